@@ -1,0 +1,153 @@
+/*
+ * stereo_hip.h -- C ABI of the MI355X (gfx950) stereo-matching layer.
+ *
+ * This is the drop-in boundary for the reference's one data-parallel hot path
+ * (per-shift match cost -> S x S window aggregation -> winner-take-all) plus
+ * the stages either side of it.  Plain C: opaque plan handle, raw pointers,
+ * sizes and a stream handle (a hipStream_t passed as void *, NULL = default
+ * stream).  No C++ or torch types cross it.  The reference has no FFI of its
+ * own: its boundary is main()/algorithm() calling file-local kernels, so each
+ * entry point names the reference code it replaces (paths relative to
+ * /root/reference).  INTEGRATION.md shows the reference-side call sites.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero (an SM_ERR_* code) on
+ *     failure; sm_last_error() then returns a message for the calling thread.
+ *     The reference's convention on any GPU API failure is "message on
+ *     stderr, exit(EXIT_FAILURE)" (src/helper_cuda.h:890-901); callers keep
+ *     that by printing sm_last_error() and exiting 1.
+ *   - d_* pointers are device (HBM) addresses owned by the caller; the plan
+ *     owns only its private workspace.
+ *   - launches are asynchronous on the given stream; nothing here
+ *     synchronises except sm_stream_sync, sm_memcpy_* and sm_plan_status.
+ *   - images are row-major, W*H elements, no padding.  A batch of pairs is
+ *     `pairs` consecutive images.  The ghost-border variant needs no padded
+ *     arrays (src/ghost.h): the halo is synthesised inside the kernels.
+ */
+#ifndef STEREO_HIP_H
+#define STEREO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SM_OK            0
+#define SM_ERR_ARG       1 /* invalid argument */
+#define SM_ERR_HIP       2 /* a HIP runtime call or a launch failed */
+#define SM_ERR_NOMEM     3 /* device or host allocation failed */
+#define SM_ERR_ZERO_DIV  4 /* contour interval is 0 (the reference traps: SIGFPE) */
+
+/* border handling: stereo.c (wrap-around idx(), src/util.h:42-47) or
+ * stereo-ghost.c (zero / 128.0 halos, src/stereo-ghost.c:286-287,:384-385) */
+enum sm_border { SM_TOROIDAL = 0, SM_GHOST = 1 };
+
+typedef struct sm_plan sm_plan;
+
+/* message for the last failure on this thread ("" if none) */
+const char *sm_last_error(void);
+
+/* number of visible HIP devices */
+int sm_device_count(int *count);
+
+/* ---- device memory helpers (what ALLOCATE_GPU / MAKE_GPU_COPY /
+ * MAKE_HOST_COPY of src/util.h:119-152 did; buffers come back zero-filled
+ * like cuda_xmalloc, src/util.h:119-129) -------------------------------- */
+int sm_malloc(int device, size_t bytes, void **d_ptr);
+int sm_free(int device, void *d_ptr);
+int sm_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
+int sm_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
+int sm_stream_sync(int device, void *stream);
+
+/* ---- plan: geometry + private workspace for one image size ------------- *
+ * num_shifts  = the reference's compile-time NUM_SHIFTS (src/stereo.c:6),
+ *               here a run-time value, 1..65535
+ * square_width = argv[4] of the reference (src/stereo.c:365); the window is
+ *               (2*(square_width/2)+1)^2; 0 <= square_width <= min(W,H)
+ *               (src/stereo.c:382-385)
+ * max_pairs   = largest batch a single call will be given (>= 1)          */
+int sm_plan_create(int device, int width, int height, int num_shifts,
+                   int square_width, int border, int max_pairs, sm_plan **out);
+void sm_plan_destroy(sm_plan *plan);
+
+/* human-readable description of the kernel variant and tiling the plan
+ * selected (for logs / bench.py); the string lives as long as the plan */
+const char *sm_plan_describe(const sm_plan *plan);
+/* bytes of private device workspace */
+size_t sm_plan_workspace_bytes(const sm_plan *plan);
+
+/* ---- step 1: edges ------------------------------------------------------ *
+ * replaces find_all_edges<<<>>> (src/stereo.cu:27-92, ghost twin
+ * src/stereo-ghost.cu) for `pairs` x 2 images.  Input is uint8 gray (the
+ * reference's double brightness is k/256.0, src/image.c:9-15; the decision
+ * is evaluated in the same IEEE double arithmetic).  Writes the packed edge
+ * bits the hot path consumes into the plan workspace and, when d_edges_* are
+ * non-NULL, the reference's u8 {0,1} edge images as well.                  */
+int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
+                  const uint8_t *d_gray_right, double threshold, int pairs,
+                  uint8_t *d_edges_left, uint8_t *d_edges_right, void *stream);
+
+/* alternative entry to the hot path for callers that already hold u8 {0,1}
+ * edge images (the arguments of fillup_matches, src/stereo.cu:127): packs
+ * them into the plan workspace                                              */
+int sm_load_edges(sm_plan *plan, const uint8_t *d_edges_left,
+                  const uint8_t *d_edges_right, int pairs, void *stream);
+
+/* ---- step 2: THE HOT PATH ---------------------------------------------- *
+ * one fused launch that replaces fillup_matches (src/stereo.cu:127-137),
+ * the NUM_SHIFTS x {cudaMemset, addup_pixels_in_square, record_score} loop
+ * (src/stereo.cu:142-207) and find_highest_scoring_shifts
+ * (src/stereo.cu:211-225), for the edges last given to sm_find_edges /
+ * sm_load_edges.  d_web receives the winning shift 1..num_shifts per pixel
+ * (int32, the reference's `web`); d_best, if non-NULL, the winning masked
+ * score (the reference's `buf`, dumped as score_best-0).                    */
+int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d_best,
+                 void *stream);
+
+/* steps 1 + 2 back to back: uint8 pairs in, web out */
+int sm_run(sm_plan *plan, const uint8_t *d_gray_left,
+           const uint8_t *d_gray_right, double threshold, int pairs,
+           int32_t *d_web, int32_t *d_best, void *stream);
+
+/* debug tap: materialise the per-shift planes the reference dumps in debug
+ * builds (matches-i, score_all-i, scores-i; src/stereo.c:98-104,:158-164,
+ * :189) for one shift of one pair.  Any output may be NULL.  Slow path.    */
+int sm_debug_planes(sm_plan *plan, int pair, int shift, uint8_t *d_match,
+                    int32_t *d_score_all, int32_t *d_scores, void *stream);
+
+/* debug tap: the device's edge decision (the 3-vs-3 contrast test of
+ * src/stereo.c:19-27) for EVERY pair of in-image side sums: d_table receives
+ * 766*766 bytes, table[sa*766+sb] in {0,1}, sums in units of 1/256.  Lets a
+ * test prove the device arithmetic equals the host's for a threshold.       */
+int sm_debug_edge_table(int device, double threshold, uint8_t *d_table, void *stream);
+
+/* ---- step 3 -------------------------------------------------------------- *
+ * fill_web_holes (src/stereo.cu:235-256): `times` Jacobi sweeps over pixels
+ * that are 0, ping-ponging d_web and d_tmp exactly as the reference swaps
+ * its pointers; *result_in_tmp tells which buffer holds the returned image.
+ * Both buffers are W*H int32 per pair.                                      */
+int sm_fill_web_holes(sm_plan *plan, int32_t *d_web, int32_t *d_tmp, int times,
+                      int pairs, int *result_in_tmp, void *stream);
+
+/* array_min_gpu / array_max_gpu (src/util.cu:15-45) of each pair's image;
+ * d_minmax receives 2 int32 per pair: {min, max}                            */
+int sm_min_max(sm_plan *plan, const int32_t *d_image, int pairs,
+               int32_t *d_minmax, void *stream);
+
+/* draw_contour_map_kernel (src/stereo.cu:261-285) with the min/max taken
+ * from d_minmax (as written by sm_min_max).  A zero interval (the reference
+ * divides by it) is recorded in the plan and reported by sm_plan_status.    */
+int sm_draw_contour_map(sm_plan *plan, const int32_t *d_web,
+                        const int32_t *d_minmax, int num_lines, int pairs,
+                        uint8_t *d_out, void *stream);
+
+/* synchronises the stream and returns SM_ERR_ZERO_DIV if a contour launch
+ * since the last call met a zero interval, else SM_OK                       */
+int sm_plan_status(sm_plan *plan, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,74 @@
+"""Build the native pieces in-tree.
+
+    python -m stereomatching_amd.build            # HIP library (+ oracle checker)
+
+libstereo_hip.so is built with hipcc for gfx950 only (cross-compiles without a
+GPU) and lands next to this file so that it travels with the source tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libstereo_hip.so"
+SOURCES = ["sm_api.hip", "sm_match.hip"]
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # the edge test must round exactly like the reference's C doubles
+    "-ffp-contract=off",
+    "-Wall", "-Wno-unused-result",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH and /opt/rocm/bin)")
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> Path:
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "sm_internal.h", ROOT / "include" / "stereo_hip.h"]
+    if force or _stale(LIB, deps):
+        cmd = [_hipcc(), *HIPCC_FLAGS, f"-I{ROOT / 'include'}", f"-I{CSRC}",
+               *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle(verbose: bool = False) -> None:
+    """The CPU checker (oracle/liboracle.so) and, where /root/reference exists,
+    the compiled reference under oracle/_ref.  Building the checker is not
+    using it: nothing in this package loads either."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "liboracle.so"], stdout=out)
+    if Path("/root/reference/src").is_dir():
+        subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "ref"], stdout=out)
+
+
+def build_host(verbose: bool = False) -> None:
+    """The C command-line programs (stereopar, stereopar-ghost, ...)."""
+    out = None if verbose else subprocess.DEVNULL
+    if (ROOT / "Makefile").exists():
+        subprocess.check_call(["make", "-C", str(ROOT), "build=timing"], stdout=out)
+
+
+if __name__ == "__main__":
+    build_hip(force="--force" in sys.argv, verbose=True)
+    build_oracle(verbose=True)
+    print("built", LIB)

@@ -1,0 +1,85 @@
+"""ctypes binding of include/stereo_hip.h (libstereo_hip.so).
+
+This is the only way the Python host side reaches the kernels, and it is the
+same C ABI a C caller links against.  There is no fallback: if the library is
+missing or does not export a declared symbol, importing fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libstereo_hip.so"
+HEADER = PKG.parent / "include" / "stereo_hip.h"
+
+SM_OK, SM_ERR_ARG, SM_ERR_HIP, SM_ERR_NOMEM, SM_ERR_ZERO_DIV = range(5)
+SM_TOROIDAL, SM_GHOST = 0, 1
+BORDERS = {"toroidal": SM_TOROIDAL, "ghost": SM_GHOST}
+
+
+class StereoHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[sm error {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/stereo_hip.h declares."""
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(sm_[a-z0-9_]+)\s*\(", text)))
+
+
+_vp, _int, _sz, _dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_double
+_intp = C.POINTER(C.c_int)
+
+_SIGNATURES = {
+    "sm_last_error": (C.c_char_p, []),
+    "sm_device_count": (_int, [_intp]),
+    "sm_malloc": (_int, [_int, _sz, C.POINTER(_vp)]),
+    "sm_free": (_int, [_int, _vp]),
+    "sm_memcpy_h2d": (_int, [_int, _vp, _vp, _sz]),
+    "sm_memcpy_d2h": (_int, [_int, _vp, _vp, _sz]),
+    "sm_stream_sync": (_int, [_int, _vp]),
+    "sm_plan_create": (_int, [_int, _int, _int, _int, _int, _int, _int, C.POINTER(_vp)]),
+    "sm_plan_destroy": (None, [_vp]),
+    "sm_plan_describe": (C.c_char_p, [_vp]),
+    "sm_plan_workspace_bytes": (_sz, [_vp]),
+    "sm_find_edges": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp]),
+    "sm_load_edges": (_int, [_vp, _vp, _vp, _int, _vp]),
+    "sm_match_wta": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "sm_run": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp]),
+    "sm_debug_planes": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp]),
+    "sm_debug_edge_table": (_int, [_int, _dbl, _vp, _vp]),
+    "sm_fill_web_holes": (_int, [_vp, _vp, _vp, _int, _int, _intp, _vp]),
+    "sm_min_max": (_int, [_vp, _vp, _int, _vp, _vp]),
+    "sm_draw_contour_map": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),
+    "sm_plan_status": (_int, [_vp, _vp]),
+}
+
+
+def _load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -m stereomatching_amd.build` (needs hipcc; cross-compiles for gfx950 "
+            "without a GPU). There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} does not export {missing} declared in {HEADER}")
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != SM_OK:
+        raise StereoHipError(rc, lib.sm_last_error().decode(errors="replace"))

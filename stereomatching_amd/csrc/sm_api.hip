@@ -1,0 +1,549 @@
+// sm_api.hip -- C-ABI entry points (include/stereo_hip.h) and the small
+// kernels around the hot path: edge detection straight into the packed ext
+// image, u8 -> ext packing, the debug tap, and step 3 (hole fill, min/max,
+// contour).  The hot path itself is sm_match.hip.
+
+#include "sm_internal.h"
+
+#include <limits.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+
+static thread_local char g_err[512] = "";
+
+int sm_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *sm_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------
+// step 1: edges, written directly in the hot path's packed format
+// ---------------------------------------------------------------------------
+
+// The 3-vs-3 contrast test of src/stereo.c:19-27 on integer side sums in
+// units of 1/256 (brightness is k/256.0, src/image.c:9-15; the ghost halo
+// 128.0 is 32768).  A three-term sum of such values is exact in double, so
+// (a+b+c)/3.0 == sum/768.0 with a single rounding, and every later operation
+// is one IEEE operation exactly as in the C source.  Built with
+// -ffp-contract=off; tests/test_edges.py checks all 766*766 in-image sum
+// pairs against the host's arithmetic.
+__device__ __forceinline__ bool contrast_test(int sa, int sb, double threshold)
+{
+    const double ma = (double)sa / 768.0;
+    const double mb = (double)sb / 768.0;
+    const double overall = (ma + mb) / 2.0;
+    double limit = threshold * overall;
+    limit = limit > 0.0 ? limit : 0.0;
+    limit = limit < 1.0 ? limit : 1.0;
+    return fabs(ma - mb) > limit;
+}
+
+__device__ __forceinline__ int pos_mod(int v, int m)
+{
+    int r = v % m;
+    return r < 0 ? r + m : r;
+}
+
+// edge value of image pixel (x, y), 0 <= x < w, 0 <= y < h
+__device__ __forceinline__ u32 edge_at(const u8 *__restrict__ gray, int w, int h, int x, int y,
+                                       double threshold, bool ghost)
+{
+    int v[3][3];
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            int xx = x + dx, yy = y + dy;
+            int val;
+            if (ghost) {
+                const bool in = xx >= 0 && xx < w && yy >= 0 && yy < h;
+                val = in ? gray[(size_t)yy * w + xx] : 32768;
+            } else {
+                xx = xx < 0 ? w - 1 : (xx >= w ? 0 : xx);
+                yy = yy < 0 ? h - 1 : (yy >= h ? 0 : yy);
+                val = gray[(size_t)yy * w + xx];
+            }
+            v[dy + 1][dx + 1] = val;
+        }
+    }
+    // v[row][col]: row 0 = y-1, col 0 = x-1
+    // left | right                       src/stereo.c:16-28
+    if (contrast_test(v[0][0] + v[1][0] + v[2][0], v[0][2] + v[1][2] + v[2][2], threshold)) return 1;
+    // top | bottom                       src/stereo.c:30-42
+    if (contrast_test(v[0][0] + v[0][1] + v[0][2], v[2][0] + v[2][1] + v[2][2], threshold)) return 1;
+    // up-left | down-right               src/stereo.c:44-56
+    if (contrast_test(v[0][0] + v[0][1] + v[1][0], v[1][2] + v[2][1] + v[2][2], threshold)) return 1;
+    // down-left | up-right               src/stereo.c:58-70
+    if (contrast_test(v[2][0] + v[2][1] + v[1][0], v[0][1] + v[0][2] + v[1][2], threshold)) return 1;
+    return 0;
+}
+
+__global__ void k_edge_table(double threshold, u8 *__restrict__ table)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x, sa = blockIdx.y;
+    if (sb < 766) table[sa * 766 + sb] = contrast_test(sa, sb, threshold);
+}
+
+// One lane per ext pixel; a wave's 64 decisions become two ext words via
+// ballot.  FROM_GRAY: run the edge test; otherwise read a u8 {0,1} edge image.
+template <bool FROM_GRAY>
+__global__ __launch_bounds__(256) void k_fill_ext(const u8 *__restrict__ src_l,
+                                                  const u8 *__restrict__ src_r,
+                                                  u8 *__restrict__ edges_l,
+                                                  u8 *__restrict__ edges_r,
+                                                  u32 *__restrict__ ext, const MatchGeom g,
+                                                  double threshold, int ghost)
+{
+    const int xe = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ye = blockIdx.y;
+    const int pair = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const size_t img = (size_t)pair * g.w * g.h;
+    const u8 *src = (side ? src_r : src_l) + img;
+    u8 *edges = side ? edges_r : edges_l;
+
+    const int x = xe - g.pad_l, y = ye - g.half;
+    const bool inside = x >= 0 && x < g.w && y >= 0 && y < g.h;
+    u32 val = 0;
+    if (xe < g.ext_words * 32) {
+        if (inside || !ghost) {
+            const int xs = inside ? x : pos_mod(x, g.w);
+            const int ys = inside ? y : pos_mod(y, g.h);
+            if (FROM_GRAY)
+                val = edge_at(src, g.w, g.h, xs, ys, threshold, ghost != 0);
+            else
+                val = src[(size_t)ys * g.w + xs] != 0;
+        }
+        if (FROM_GRAY && inside && edges) edges[img + (size_t)y * g.w + x] = (u8)val;
+    }
+    const unsigned long long bal = __ballot(val != 0);
+    if ((threadIdx.x & 63) == 0) {
+        u32 *row = ext + ((size_t)blockIdx.z * g.ext_rows + ye) * g.ext_words;
+        const int wd = xe >> 5;
+        if (wd < g.ext_words) row[wd] = (u32)bal;
+        if (wd + 1 < g.ext_words) row[wd + 1] = (u32)(bal >> 32);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// debug tap: the per-shift planes of the reference's debug build
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_debug_planes(const u32 *__restrict__ ext, int pair,
+                                                      int shift, u8 *__restrict__ match,
+                                                      i32 *__restrict__ score_all,
+                                                      i32 *__restrict__ scores, const MatchGeom g,
+                                                      int ghost)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= g.w) return;
+    const u32 *ext_l = ext + (size_t)pair * 2 * g.ext_image_words;
+    const u32 *ext_r = ext_l + g.ext_image_words;
+    auto bit = [&](const u32 *im, int xx, int yy) -> u32 {
+        const int b = xx + g.pad_l;
+        return (im[(size_t)(yy + g.half) * g.ext_words + (b >> 5)] >> (b & 31)) & 1u;
+    };
+    int xa = x - g.half, xb = x + g.half, ya = y - g.half, yb = y + g.half;
+    if (ghost) {
+        xa = max(xa, 0); xb = min(xb, g.w - 1);
+        ya = max(ya, 0); yb = min(yb, g.h - 1);
+    }
+    i32 sum = 0;
+    for (int yy = ya; yy <= yb; yy++)
+        for (int xx = xa; xx <= xb; xx++)
+            sum += bit(ext_l, xx, yy) == bit(ext_r, xx + shift, yy);
+    const u32 m = bit(ext_l, x, y) == bit(ext_r, x + shift, y);
+    const size_t o = (size_t)y * g.w + x;
+    if (match) match[o] = (u8)m;
+    if (score_all) score_all[o] = sum;
+    if (scores) scores[o] = m ? sum : 0;
+}
+
+// ---------------------------------------------------------------------------
+// step 3
+// ---------------------------------------------------------------------------
+
+// one Jacobi sweep of src/stereo.cu:235-245: read `oth`, write `cur` where
+// oth == 0.  Neighbours at flat offsets +-1, +-w (the reference's unwrapped
+// IDX); offsets that leave the image array are undefined in the reference and
+// read as 0 here.
+__global__ __launch_bounds__(256) void k_fill_holes_step(i32 *__restrict__ cur,
+                                                         const i32 *__restrict__ oth, int w,
+                                                         long long n)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const size_t base = (size_t)blockIdx.y * n;
+    if (oth[base + p] == 0) {
+        const i32 r = p + 1 < n ? oth[base + p + 1] : 0;
+        const i32 u = p + w < n ? oth[base + p + w] : 0;
+        const i32 l = p - 1 >= 0 ? oth[base + p - 1] : 0;
+        const i32 d = p - w >= 0 ? oth[base + p - w] : 0;
+        cur[base + p] = (r + u + l + d) / 4;
+    }
+}
+
+__global__ void k_count_zeros(const i32 *__restrict__ a, long long total, i32 *__restrict__ flag)
+{
+    bool z = false;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+         p += (long long)gridDim.x * blockDim.x)
+        z |= a[p] == 0;
+    if (__ballot(z) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ void k_minmax_init(i32 *__restrict__ mm, int pairs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pairs) { mm[2 * i] = INT_MAX; mm[2 * i + 1] = INT_MIN; }
+}
+
+__global__ __launch_bounds__(256) void k_minmax(const i32 *__restrict__ a, long long n,
+                                                i32 *__restrict__ mm)
+{
+    const size_t base = (size_t)blockIdx.y * n;
+    i32 lo = INT_MAX, hi = INT_MIN;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (long long)gridDim.x * blockDim.x) {
+        const i32 v = a[base + p];
+        lo = min(lo, v);
+        hi = max(hi, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        hi = max(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[2 * blockIdx.y], lo);
+        atomicMax(&mm[2 * blockIdx.y + 1], hi);
+    }
+}
+
+// src/stereo.cu:261-274
+__global__ __launch_bounds__(256) void k_contour(const i32 *__restrict__ web,
+                                                 const i32 *__restrict__ mm, int lines,
+                                                 long long n, u8 *__restrict__ out,
+                                                 i32 *__restrict__ flags)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const size_t base = (size_t)blockIdx.y * n;
+    const i32 lo = mm[2 * blockIdx.y], hi = mm[2 * blockIdx.y + 1];
+    const i32 interval = lines != 0 ? (hi - lo) / lines : 0;
+    if (interval == 0) {
+        if (p == 0) atomicOr(&flags[0], 1);
+        out[base + p] = 0;
+        return;
+    }
+    out[base + p] = (u8)(((web[base + p] - lo) % interval) == 0);
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+
+static int use_device(int device)
+{
+    SM_HIP(hipSetDevice(device));
+    return SM_OK;
+}
+#define SM_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+extern "C" int sm_device_count(int *count)
+{
+    if (!count) return sm_fail(SM_ERR_ARG, "sm_device_count: count is NULL");
+    SM_HIP(hipGetDeviceCount(count));
+    return SM_OK;
+}
+
+extern "C" int sm_malloc(int device, size_t bytes, void **d_ptr)
+{
+    if (!d_ptr) return sm_fail(SM_ERR_ARG, "sm_malloc: d_ptr is NULL");
+    SM_TRY(use_device(device));
+    *d_ptr = nullptr;
+    SM_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    SM_HIP(hipMemset(*d_ptr, 0, bytes ? bytes : 1));
+    return SM_OK;
+}
+
+extern "C" int sm_free(int device, void *d_ptr)
+{
+    SM_TRY(use_device(device));
+    SM_HIP(hipFree(d_ptr));
+    return SM_OK;
+}
+
+extern "C" int sm_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes)
+{
+    SM_TRY(use_device(device));
+    SM_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return SM_OK;
+}
+
+extern "C" int sm_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes)
+{
+    SM_TRY(use_device(device));
+    SM_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return SM_OK;
+}
+
+extern "C" int sm_stream_sync(int device, void *stream)
+{
+    SM_TRY(use_device(device));
+    SM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SM_OK;
+}
+
+extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
+                              int square_width, int border, int max_pairs, sm_plan **out)
+{
+    if (!out) return sm_fail(SM_ERR_ARG, "sm_plan_create: out is NULL");
+    *out = nullptr;
+    if (width < 1 || height < 1)
+        return sm_fail(SM_ERR_ARG, "sm_plan_create: image size %dx%d is not positive", width, height);
+    if ((long long)width * height > (1ll << 30))
+        return sm_fail(SM_ERR_ARG, "sm_plan_create: image of %dx%d pixels is too large", width, height);
+    if (num_shifts < 1 || num_shifts > 65535)
+        return sm_fail(SM_ERR_ARG, "sm_plan_create: num_shifts %d outside 1..65535", num_shifts);
+    if (square_width < 0)
+        return sm_fail(SM_ERR_ARG, "sm_plan_create: square_width %d is negative "
+                       "(undefined in the reference)", square_width);
+    if (square_width > width || square_width > height)
+        return sm_fail(SM_ERR_ARG, "error: square width must not be higher than image width/height");
+    if (border != SM_TOROIDAL && border != SM_GHOST)
+        return sm_fail(SM_ERR_ARG, "sm_plan_create: border %d is neither SM_TOROIDAL nor SM_GHOST", border);
+    if (max_pairs < 1)
+        return sm_fail(SM_ERR_ARG, "sm_plan_create: max_pairs %d < 1", max_pairs);
+    SM_TRY(use_device(device));
+
+    sm_plan *p = (sm_plan *)calloc(1, sizeof *p);
+    if (!p) return sm_fail(SM_ERR_NOMEM, "error: out of memory");
+    p->device = device;
+    p->width = width; p->height = height;
+    p->num_shifts = num_shifts; p->square_width = square_width;
+    p->border = border; p->max_pairs = max_pairs;
+    int rc = sm_match_configure(p);
+    if (rc) { free(p); return rc; }
+
+    p->ext_bytes = (size_t)max_pairs * 2 * (size_t)p->g.ext_image_words * sizeof(u32);
+    hipError_t e = hipMalloc((void **)&p->d_ext, p->ext_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_flags, 4 * sizeof(i32));
+    if (e == hipSuccess) e = hipMemset(p->d_ext, 0, p->ext_bytes);
+    if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(i32));
+    if (e != hipSuccess) {
+        if (p->d_ext) (void)hipFree(p->d_ext);
+        if (p->d_flags) (void)hipFree(p->d_flags);
+        free(p);
+        return sm_fail(e == hipErrorOutOfMemory ? SM_ERR_NOMEM : SM_ERR_HIP,
+                       "sm_plan_create: workspace allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return SM_OK;
+}
+
+extern "C" void sm_plan_destroy(sm_plan *plan)
+{
+    if (!plan) return;
+    (void)hipSetDevice(plan->device);
+    (void)hipFree(plan->d_ext);
+    (void)hipFree(plan->d_flags);
+    free(plan);
+}
+
+extern "C" const char *sm_plan_describe(const sm_plan *plan) { return plan ? plan->describe : ""; }
+
+extern "C" size_t sm_plan_workspace_bytes(const sm_plan *plan)
+{
+    return plan ? plan->ext_bytes + 4 * sizeof(i32) : 0;
+}
+
+static int check_plan_pairs(const sm_plan *plan, int pairs, const char *who)
+{
+    if (!plan) return sm_fail(SM_ERR_ARG, "%s: plan is NULL", who);
+    if (pairs < 1 || pairs > plan->max_pairs)
+        return sm_fail(SM_ERR_ARG, "%s: pairs %d outside 1..%d (max_pairs of the plan)", who, pairs,
+                       plan->max_pairs);
+    return SM_OK;
+}
+
+template <bool FROM_GRAY>
+static int fill_ext(sm_plan *plan, const u8 *l, const u8 *r, double threshold, int pairs,
+                    u8 *el, u8 *er, hipStream_t st)
+{
+    const MatchGeom &g = plan->g;
+    const dim3 grid((g.ext_words * 32 + 255) / 256, g.ext_rows, pairs * 2), block(256);
+    hipLaunchKernelGGL((k_fill_ext<FROM_GRAY>), grid, block, 0, st, l, r, el, er, plan->d_ext, g,
+                       threshold, plan->border == SM_GHOST ? 1 : 0);
+    SM_LAUNCH_CHECK("k_fill_ext");
+    plan->pairs_loaded = pairs;
+    return SM_OK;
+}
+
+extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
+                             const uint8_t *d_gray_right, double threshold, int pairs,
+                             uint8_t *d_edges_left, uint8_t *d_edges_right, void *stream)
+{
+    SM_TRY(check_plan_pairs(plan, pairs, "sm_find_edges"));
+    if (!d_gray_left || !d_gray_right)
+        return sm_fail(SM_ERR_ARG, "sm_find_edges: input image pointer is NULL");
+    if (!(threshold >= 0.0 && threshold <= 1.0))
+        return sm_fail(SM_ERR_ARG, "error: threshold must be between 0 and 1");
+    SM_TRY(use_device(plan->device));
+    return fill_ext<true>(plan, d_gray_left, d_gray_right, threshold, pairs, d_edges_left,
+                          d_edges_right, (hipStream_t)stream);
+}
+
+extern "C" int sm_load_edges(sm_plan *plan, const uint8_t *d_edges_left,
+                             const uint8_t *d_edges_right, int pairs, void *stream)
+{
+    SM_TRY(check_plan_pairs(plan, pairs, "sm_load_edges"));
+    if (!d_edges_left || !d_edges_right)
+        return sm_fail(SM_ERR_ARG, "sm_load_edges: edge image pointer is NULL");
+    SM_TRY(use_device(plan->device));
+    return fill_ext<false>(plan, d_edges_left, d_edges_right, 0.0, pairs, nullptr, nullptr,
+                           (hipStream_t)stream);
+}
+
+extern "C" int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d_best,
+                            void *stream)
+{
+    SM_TRY(check_plan_pairs(plan, pairs, "sm_match_wta"));
+    if (!d_web) return sm_fail(SM_ERR_ARG, "sm_match_wta: d_web is NULL");
+    if (pairs > plan->pairs_loaded)
+        return sm_fail(SM_ERR_ARG, "sm_match_wta: %d pairs requested but edges of only %d are loaded "
+                       "(call sm_find_edges or sm_load_edges first)", pairs, plan->pairs_loaded);
+    SM_TRY(use_device(plan->device));
+    return sm_match_launch(plan, pairs, d_web, d_best, (hipStream_t)stream);
+}
+
+extern "C" int sm_run(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
+                      double threshold, int pairs, int32_t *d_web, int32_t *d_best, void *stream)
+{
+    SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, stream));
+    return sm_match_wta(plan, pairs, d_web, d_best, stream);
+}
+
+extern "C" int sm_debug_planes(sm_plan *plan, int pair, int shift, uint8_t *d_match,
+                               int32_t *d_score_all, int32_t *d_scores, void *stream)
+{
+    if (!plan) return sm_fail(SM_ERR_ARG, "sm_debug_planes: plan is NULL");
+    if (pair < 0 || pair >= plan->pairs_loaded)
+        return sm_fail(SM_ERR_ARG, "sm_debug_planes: pair %d not loaded (%d loaded)", pair,
+                       plan->pairs_loaded);
+    if (shift < 0 || shift >= plan->num_shifts)
+        return sm_fail(SM_ERR_ARG, "sm_debug_planes: shift %d outside 0..%d", shift,
+                       plan->num_shifts - 1);
+    SM_TRY(use_device(plan->device));
+    const MatchGeom &g = plan->g;
+    const dim3 grid((g.w + 255) / 256, g.h), block(256);
+    hipLaunchKernelGGL(k_debug_planes, grid, block, 0, (hipStream_t)stream, plan->d_ext, pair, shift,
+                       d_match, d_score_all, d_scores, g, plan->border == SM_GHOST ? 1 : 0);
+    SM_LAUNCH_CHECK("k_debug_planes");
+    return SM_OK;
+}
+
+extern "C" int sm_debug_edge_table(int device, double threshold, uint8_t *d_table, void *stream)
+{
+    if (!d_table) return sm_fail(SM_ERR_ARG, "sm_debug_edge_table: d_table is NULL");
+    SM_TRY(use_device(device));
+    hipLaunchKernelGGL(k_edge_table, dim3(3, 766), dim3(256), 0, (hipStream_t)stream, threshold,
+                       d_table);
+    SM_LAUNCH_CHECK("k_edge_table");
+    return SM_OK;
+}
+
+extern "C" int sm_fill_web_holes(sm_plan *plan, int32_t *d_web, int32_t *d_tmp, int times,
+                                 int pairs, int *result_in_tmp, void *stream)
+{
+    SM_TRY(check_plan_pairs(plan, pairs, "sm_fill_web_holes"));
+    if (!d_web || !d_tmp || !result_in_tmp)
+        return sm_fail(SM_ERR_ARG, "sm_fill_web_holes: NULL argument");
+    SM_TRY(use_device(plan->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)plan->width * plan->height;
+    *result_in_tmp = 0;
+    if (times <= 0) return SM_OK;
+
+    // The sweeps only ever change pixels that are 0.  The web the hot path
+    // produces is >= 1 everywhere (a winning shift is recorded as shift+1), so
+    // in the pipeline this stage is the identity; one
+    // pass over the image decides that, as the reference's array_min_gpu
+    // round trip does for the contour stage.
+    SM_HIP(hipMemsetAsync(&plan->d_flags[1], 0, sizeof(i32), st));
+    hipLaunchKernelGGL(k_count_zeros, dim3(1024), dim3(256), 0, st, d_web, n * pairs,
+                       &plan->d_flags[1]);
+    SM_LAUNCH_CHECK("k_count_zeros");
+    i32 has_zero = 0;
+    SM_HIP(hipMemcpyAsync(&has_zero, &plan->d_flags[1], sizeof(i32), hipMemcpyDeviceToHost, st));
+    SM_HIP(hipStreamSynchronize(st));
+    if (!has_zero) return SM_OK;
+
+    // tmp <- web, then `times` sweeps with the two buffers trading places
+    // (src/stereo.cu:247-256,:328)
+    SM_HIP(hipMemcpyAsync(d_tmp, d_web, sizeof(i32) * n * pairs, hipMemcpyDeviceToDevice, st));
+    i32 *cur = d_web, *oth = d_tmp;
+    const dim3 grid((unsigned)((n + 255) / 256), pairs), block(256);
+    for (int i = 0; i < times; i++) {
+        hipLaunchKernelGGL(k_fill_holes_step, grid, block, 0, st, cur, oth, plan->width, n);
+        i32 *t = cur; cur = oth; oth = t;
+    }
+    SM_LAUNCH_CHECK("k_fill_holes_step");
+    *result_in_tmp = cur == d_tmp;
+    return SM_OK;
+}
+
+extern "C" int sm_min_max(sm_plan *plan, const int32_t *d_image, int pairs, int32_t *d_minmax,
+                          void *stream)
+{
+    SM_TRY(check_plan_pairs(plan, pairs, "sm_min_max"));
+    if (!d_image || !d_minmax) return sm_fail(SM_ERR_ARG, "sm_min_max: NULL argument");
+    SM_TRY(use_device(plan->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)plan->width * plan->height;
+    hipLaunchKernelGGL(k_minmax_init, dim3((pairs + 63) / 64), dim3(64), 0, st, d_minmax, pairs);
+    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(k_minmax, dim3(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), pairs),
+                       dim3(256), 0, st, d_image, n, d_minmax);
+    SM_LAUNCH_CHECK("k_minmax");
+    return SM_OK;
+}
+
+extern "C" int sm_draw_contour_map(sm_plan *plan, const int32_t *d_web, const int32_t *d_minmax,
+                                   int num_lines, int pairs, uint8_t *d_out, void *stream)
+{
+    SM_TRY(check_plan_pairs(plan, pairs, "sm_draw_contour_map"));
+    if (!d_web || !d_minmax || !d_out)
+        return sm_fail(SM_ERR_ARG, "sm_draw_contour_map: NULL argument");
+    SM_TRY(use_device(plan->device));
+    const long long n = (long long)plan->width * plan->height;
+    hipLaunchKernelGGL(k_contour, dim3((unsigned)((n + 255) / 256), pairs), dim3(256), 0,
+                       (hipStream_t)stream, d_web, d_minmax, num_lines, n, d_out, plan->d_flags);
+    SM_LAUNCH_CHECK("k_contour");
+    return SM_OK;
+}
+
+extern "C" int sm_plan_status(sm_plan *plan, void *stream)
+{
+    if (!plan) return sm_fail(SM_ERR_ARG, "sm_plan_status: plan is NULL");
+    SM_TRY(use_device(plan->device));
+    hipStream_t st = (hipStream_t)stream;
+    i32 flag = 0;
+    SM_HIP(hipMemcpyAsync(&flag, &plan->d_flags[0], sizeof(i32), hipMemcpyDeviceToHost, st));
+    SM_HIP(hipMemsetAsync(&plan->d_flags[0], 0, sizeof(i32), st));
+    SM_HIP(hipStreamSynchronize(st));
+    if (flag)
+        return sm_fail(SM_ERR_ZERO_DIV, "contour interval is zero ((max-min)/lines == 0): the "
+                       "reference divides by it");
+    return SM_OK;
+}

@@ -1,0 +1,91 @@
+// sm_internal.h -- shared between the translation units of libstereo_hip.so.
+// Not part of the public boundary (that is include/stereo_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "stereo_hip.h"
+
+typedef uint32_t u32;
+typedef uint8_t u8;
+typedef int32_t i32;
+
+// ---------------------------------------------------------------------------
+// Packed edge image ("ext image"), the hot path's input format in HBM.
+//
+// One bit per pixel, 32 pixels per u32 word, bit b of word k of ext row e is
+// the edge value at image coordinate
+//        x = 32*k + b - pad_l,        y = e - half.
+// The image is stored with its border already applied, so the hot kernel is
+// border-mode agnostic for everything except the window's validity mask:
+//   toroidal: ext(x, y) = E(x mod W, y mod H)       (idx(), src/util.h:42-47)
+//   ghost:    ext(x, y) = E(x, y) inside the image, 0 outside
+//                                              (src/stereo-ghost.c:286-287)
+// Rows cover y in [-half, rows_needed) and x in [-pad_l, cols_needed) where
+// the needed extents include the D-shift, the window halo and tile round-up.
+// Workspace layout: [pair][side: 0 = left, 1 = right][ext_rows][ext_words].
+// ---------------------------------------------------------------------------
+
+enum { SM_KERNEL_A = 0, SM_KERNEL_B = 1, SM_KERNEL_C = 2, SM_KERNEL_GENERIC = 3 };
+
+#define SM_DSET 16   // shifts per lane in the tiled kernels
+#define SM_P 8       // pixels per lane
+#define SM_PADT 32   // left pad of a tile's LDS rows, in pixels
+#define SM_KEY_DBITS 10  // low bits of the winner key hold the shift
+
+struct MatchGeom {
+    int w, h;            // image size
+    int D;               // number of shifts
+    int n, half;         // window side (odd) and its half
+    int ext_words;       // u32 words per ext row
+    int ext_rows;        // ext rows per image
+    long long ext_image_words;  // ext_words * ext_rows
+    int pad_l;           // pixels of left pad in the ext image (multiple of 32)
+    // tiled kernels only
+    int tile_h;          // output rows per workgroup
+    int tw;              // output columns per workgroup (= 8 * runs)
+    int runs;            // pixel runs (of 8) per workgroup
+    int nl, log2nl;      // lanes that split the shift range of one run
+    int threads;         // runs * nl
+    int plw, prw;        // words per staged LDS row, left / right
+    int nsr;             // staged rows = tile_h + n - 1
+    int tiles_x, tiles_y;
+    int vec_ok;          // rows are 16-byte aligned -> int4 stores
+    int lds_bytes;
+};
+
+struct sm_plan {
+    int device;
+    int width, height, num_shifts, square_width, border, max_pairs;
+    int kernel;          // SM_KERNEL_*
+    MatchGeom g;
+    u32 *d_ext;          // packed edge images
+    size_t ext_bytes;
+    i32 *d_flags;        // [0] = zero-interval flag
+    int pairs_loaded;    // batch size of the edges currently in d_ext
+    char describe[512];
+};
+
+// error plumbing (sm_api.hip)
+int sm_fail(int code, const char *fmt, ...);
+#define SM_HIP(call)                                                          \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess)                                                 \
+            return sm_fail(e_ == hipErrorOutOfMemory ? SM_ERR_NOMEM : SM_ERR_HIP, \
+                           "%s failed: %s (%s:%d)", #call,                    \
+                           hipGetErrorString(e_), __FILE__, __LINE__);        \
+    } while (0)
+#define SM_LAUNCH_CHECK(name)                                                 \
+    do {                                                                      \
+        hipError_t e_ = hipGetLastError();                                    \
+        if (e_ != hipSuccess)                                                 \
+            return sm_fail(SM_ERR_HIP, "launch of %s failed: %s", name,       \
+                           hipGetErrorString(e_));                            \
+    } while (0)
+
+// sm_match.hip
+int sm_match_configure(sm_plan *plan);   // fills plan->kernel / plan->g
+int sm_match_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);

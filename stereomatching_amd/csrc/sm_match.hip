@@ -1,0 +1,491 @@
+// sm_match.hip -- THE HOT PATH: match cost -> S x S window sum -> masked
+// score -> winner-take-all over the shifts, fused into one launch.
+//
+// Replaces, for all D shifts at once (paths relative to /root/reference):
+//   fillup_matches                src/stereo.cu:127-137   (src/stereo.c:113-127)
+//   addup_pixels_in_square        src/stereo.cu:142-155   (src/stereo.c:132-148)
+//   record_score / fillup_scores  src/stereo.cu:185-207   (src/stereo.c:172-192)
+//   find_highest_scoring_shifts   src/stereo.cu:211-225   (src/stereo.c:196-220)
+// Closed form:
+//   m_d(x,y) = [L(x,y) == R(x+d, y)]
+//   A_d(x,y) = sum over the n x n window of m_d          (n = 2*(S/2)+1)
+//   s_d      = m_d ? A_d : 0
+//   best     = max_d s_d ;  web = 1 + max{ d : s_d == best }
+// None of the D match planes (u8) or score planes (i32) ever exists in HBM.
+//
+// Design (gfx950, wave64; integer VALU + LDS, no MFMA):
+//  * Input is the packed ext image (sm_internal.h): 1 bit per pixel with the
+//    border rule already applied, so rows are plain coalesced dword loads.
+//  * A workgroup owns a tile of tw x tile_h pixels.  It stages the tile's
+//    n-1+tile_h rows (window halo included) of L and R bits in LDS twice:
+//    plain, and "spread" (bit i of a row moved to bit 2i).
+//  * A lane owns a run of P = 8 consecutive pixels and DSET = 16 consecutive
+//    shifts and marches down the tile keeping the 128 window sums A[d][j] in
+//    registers.  The shift range of a run is split over nl = D/16 adjacent
+//    lanes; their winners are merged with DPP row operations.
+//  * Sliding the window down by one row needs  + popcount(new row's window)
+//    - popcount(old row's window).  The old row is stored complemented, so
+//    the update is  + popcount(new) + popcount(~old) - n, and because spread
+//    rows interleave (new -> even bits, old -> odd bits) both popcounts are
+//    ONE v_bfe_u32 + ONE v_bcnt_u32_b32 on a word
+//           Z_d = IL ^ (IR >> 2d)
+//    (interleaving commutes with XOR and turns a shift by d into a shift by
+//    2d, so it is done once per row in LDS, never per shift).  The "- n" is
+//    dropped: every shift of a pixel carries the same bias, which cannot
+//    change the arg-max, and is subtracted again when `best` is written.
+//  * Winner key = (A << 10 | d) masked by the centre match bit; the unsigned
+//    max of the keys is "highest score, then highest shift", the reference's
+//    last-wins rule.  A key of 0 means no shift matched -> web = D, best = 0
+//    (all scores 0, the last shift wins; src/stereo.c:211-218).
+//
+// Three instantiations by window size: A (n <= 9: Z fits 32 bits), B (n <= 16)
+// and C (n <= 25) use 64-bit Z.  Larger windows or D > 1024 take the generic
+// kernel at the bottom (correct for every input, not tuned).
+
+#include "sm_internal.h"
+
+#include <algorithm>
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ u32 spread16(u32 x)
+{
+    // bit i -> bit 2i, for the low 16 bits
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+__device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);   // ((hi:lo) >> (sh & 31)) low 32
+}
+__device__ __forceinline__ u32 ubfe(u32 v, u32 off, u32 width)
+{
+    return __builtin_amdgcn_ubfe(v, off, width);
+}
+__device__ __forceinline__ u32 sbfe1(u32 v, u32 off)
+{
+    return (u32)__builtin_amdgcn_sbfe((int)v, off, 1);   // 0 or 0xffffffff
+}
+
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_max(u32 v)
+{
+    u32 o = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return v > o ? v : o;
+}
+
+// all-reduce max over groups of nl adjacent lanes (nl uniform, power of two)
+__device__ __forceinline__ u32 group_max(u32 v, int nl)
+{
+    if (nl >= 2) v = dpp_max<0xB1>(v);    // quad_perm [1,0,3,2]
+    if (nl >= 4) v = dpp_max<0x4E>(v);    // quad_perm [2,3,0,1]
+    if (nl >= 8) v = dpp_max<0x141>(v);   // row_half_mirror
+    if (nl >= 16) v = dpp_max<0x140>(v);  // row_mirror
+    if (nl >= 32) { u32 o = (u32)__shfl_xor((int)v, 16); v = v > o ? v : o; }
+    if (nl >= 64) { u32 o = (u32)__shfl_xor((int)v, 32); v = v > o ? v : o; }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// the tiled kernel
+// ---------------------------------------------------------------------------
+
+template <int MODE, bool FULLD, bool GHOST>
+__global__ __launch_bounds__(256) void k_match_wta(const u32 *__restrict__ ext,
+                                                   i32 *__restrict__ web,
+                                                   i32 *__restrict__ best,
+                                                   const MatchGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    constexpr int ZW = MODE == SM_KERNEL_A ? 1 : 2;   // words of Z
+    constexpr int RW = ZW + 1;                          // words of the IR base
+
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.z;
+    const int tx0 = blockIdx.x * g.tw;
+    const int ty0 = blockIdx.y * g.tile_h;
+    const int n = g.n, half = g.half;
+    const int plw = g.plw, prw = g.prw, nsr = g.nsr;
+
+    const u32 *extL = ext + (size_t)pair * 2 * g.ext_image_words;
+    const u32 *extR = extL + g.ext_image_words;
+
+    u32 *pL = lds;                 // plain rows, left   [nsr][plw]
+    u32 *pR = pL + nsr * plw;      // plain rows, right  [nsr][prw]
+    u32 *sL = pR + nsr * prw;      // spread rows, left  [nsr][2*plw]
+    u32 *sR = sL + nsr * 2 * plw;  // spread rows, right [nsr][2*prw]
+
+    // ---- stage the tile (+ window halo) into LDS: coalesced dword row loads
+    {
+        const int wx0 = tx0 >> 5;   // pad_l == SM_PADT, so tile words are aligned
+        const int per_row = plw + prw;
+        for (int it = tid; it < nsr * per_row; it += blockDim.x) {
+            const int row = it / per_row;
+            const int k = it - row * per_row;
+            const bool is_r = k >= plw;
+            const int kk = is_r ? k - plw : k;
+            const u32 v = (is_r ? extR : extL)[(size_t)(ty0 + row) * g.ext_words + wx0 + kk];
+            const u32 lo = spread16(v), hi = spread16(v >> 16);
+            if (is_r) {
+                pR[row * prw + kk] = v;
+                sR[row * 2 * prw + 2 * kk] = lo;
+                sR[row * 2 * prw + 2 * kk + 1] = hi;
+            } else {
+                pL[row * plw + kk] = v;
+                sL[row * 2 * plw + 2 * kk] = lo;
+                sL[row * 2 * plw + 2 * kk + 1] = hi;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- lane role
+    const int s = tid & (g.nl - 1);       // which 16 shifts
+    const int r = tid >> g.log2nl;        // which run of 8 pixels
+    const int x0l = r * SM_P;
+    const int d0 = s * SM_DSET;
+    const int x0 = tx0 + x0l;
+
+    // bit positions inside a staged row (bit = SM_PADT + tile-local x)
+    const int bL = SM_PADT + x0l - half;  // window start, left
+    const int bR = bL + d0;               // window start, right, shift d0
+    const int wLs = (2 * bL) >> 5, shLs = (2 * bL) & 31;   // in spread rows
+    const int wRs = (2 * bR) >> 5, shRs = (2 * bR) & 31;
+    const int bLc = SM_PADT + x0l, bRc = bLc + d0;         // centre bits, plain rows
+    const int wLc = bLc >> 5, shLc = bLc & 31;
+    const int wRc = bRc >> 5, shRc = bRc & 31;
+
+    // masks for the window extraction
+    const u32 w2n = 2u * (u32)n;
+    u32 mask_b = 0;                       // MODE B: low 2n bits
+    u32 mask_c[SM_P];                     // MODE C: low 2j+2n-32 bits of Z1
+    if (MODE == SM_KERNEL_B)
+        mask_b = w2n >= 32 ? 0xffffffffu : ((1u << w2n) - 1u);
+    if (MODE == SM_KERNEL_C) {
+#pragma unroll
+        for (int j = 0; j < SM_P; j++) {
+            const u32 wj = 2 * j + w2n - 32;
+            mask_c[j] = wj >= 32 ? 0xffffffffu : ((1u << wj) - 1u);
+        }
+    }
+
+    // ghost border: which window columns lie inside the image (per lane,
+    // constant over rows), spread like the data
+    u32 cv_e[ZW];
+    if (GHOST) {
+        u32 cv = 0;
+        for (int i = 0; i < 16 * ZW; i++) {
+            const int x = x0 - half + i;
+            if (x >= 0 && x < g.w) cv |= 1u << i;
+        }
+        cv_e[0] = spread16(cv);
+        if (ZW == 2) cv_e[1] = spread16(cv >> 16);
+    }
+
+    // shifts >= D contribute nothing: clear their centre-match bits
+    u32 vb = 0xffffu;
+    if (!FULLD) {
+        const int dlim = g.D - d0;
+        vb = dlim >= SM_DSET ? 0xffffu : (dlim <= 0 ? 0u : ((1u << dlim) - 1u));
+    }
+
+    u32 A[SM_DSET][SM_P];
+#pragma unroll
+    for (int dd = 0; dd < SM_DSET; dd++)
+#pragma unroll
+        for (int j = 0; j < SM_P; j++)
+            A[dd][j] = 0;
+
+    const int rows_out = min(g.tile_h, g.h - ty0);   // >= 1
+    const int steps = rows_out + n - 1;
+
+    for (int e = 0; e < steps; e++) {
+        // ---- window rows for this step: new = staged row e, old = e - n
+        u32 il[ZW], ir[RW];
+        {
+            const u32 *rowL = sL + e * 2 * plw + wLs;
+            const u32 *rowR = sR + e * 2 * prw + wRs;
+#pragma unroll
+            for (int k = 0; k < ZW; k++) il[k] = alignbit(rowL[k + 1], rowL[k], shLs);
+#pragma unroll
+            for (int k = 0; k < RW; k++) ir[k] = alignbit(rowR[k + 1], rowR[k], shRs);
+        }
+        if (e >= n) {
+            const u32 *rowL = sL + (e - n) * 2 * plw + wLs;
+            const u32 *rowR = sR + (e - n) * 2 * prw + wRs;
+#pragma unroll
+            for (int k = 0; k < ZW; k++) il[k] |= alignbit(rowL[k + 1], rowL[k], shLs) << 1;
+#pragma unroll
+            for (int k = 0; k < RW; k++) ir[k] |= alignbit(rowR[k + 1], rowR[k], shRs) << 1;
+        }
+        // even (new) bits: flip so that 1 = match; odd (old) bits: 1 = mismatch
+#pragma unroll
+        for (int k = 0; k < ZW; k++) il[k] ^= 0x55555555u;
+
+        u32 vz[ZW];
+        if (GHOST) {
+            const int y_new = ty0 - half + e, y_old = y_new - n;
+            const bool v_new = y_new >= 0 && y_new < g.h;
+            const bool v_old = e >= n && y_old >= 0 && y_old < g.h;
+#pragma unroll
+            for (int k = 0; k < ZW; k++)
+                vz[k] = (v_new ? cv_e[k] : 0u) | (v_old ? (cv_e[k] << 1) : 0u);
+        }
+
+        // ---- accumulate: one bfe + one bcnt per (pixel, shift)
+#pragma unroll
+        for (int dd = 0; dd < SM_DSET; dd++) {
+            u32 z[ZW];
+#pragma unroll
+            for (int k = 0; k < ZW; k++) {
+                z[k] = il[k] ^ alignbit(ir[k + 1], ir[k], 2 * dd);
+                if (GHOST) z[k] &= vz[k];
+            }
+#pragma unroll
+            for (int j = 0; j < SM_P; j++) {
+                if (MODE == SM_KERNEL_A) {
+                    A[dd][j] += __builtin_popcount(ubfe(z[0], 2 * j, w2n));
+                } else if (MODE == SM_KERNEL_B) {
+                    const u32 t = j ? alignbit(z[ZW - 1], z[0], 2 * j) : z[0];
+                    A[dd][j] += __builtin_popcount(t & mask_b);
+                } else {
+                    A[dd][j] += __builtin_popcount(z[0] >> (2 * j));
+                    A[dd][j] += __builtin_popcount(z[ZW - 1] & mask_c[j]);
+                }
+            }
+        }
+
+        // ---- winner-take-all for output row t
+        if (e >= n - 1) {
+            const int t = e - (n - 1);
+            const int y = ty0 + t;
+            const u32 *rowLc = pL + (t + half) * plw + wLc;
+            const u32 *rowRc = pR + (t + half) * prw + wRc;
+            const u32 lc = alignbit(rowLc[1], rowLc[0], shLc);
+            const u32 rc = alignbit(rowRc[1], rowRc[0], shRc);
+
+            u32 key[SM_P];
+#pragma unroll
+            for (int j = 0; j < SM_P; j++) {
+                // bit (j+dd) of rj = centre match of pixel j at shift d0+dd
+                u32 rj = ~(rc ^ sbfe1(lc, j));
+                if (!FULLD) rj &= vb << j;
+                u32 k = 0;
+#pragma unroll
+                for (int dd = 0; dd < SM_DSET; dd++) {
+                    const u32 cand = ((A[dd][j] << SM_KEY_DBITS) | (u32)dd) & sbfe1(rj, j + dd);
+                    k = k > cand ? k : cand;
+                }
+                key[j] = group_max(k + (u32)d0, g.nl);
+            }
+
+            if (s == 0 && x0 < g.w) {
+                // bias carried by every A of pixel j at row t
+                int rows_in = t;          // old rows removed so far that were valid
+                if (GHOST) {
+                    const int a = max(0, ty0 - half), b = min(g.h, ty0 - half + t);
+                    rows_in = max(0, b - a);
+                }
+                i32 wv[SM_P], bv[SM_P];
+#pragma unroll
+                for (int j = 0; j < SM_P; j++) {
+                    const u32 sc = key[j] >> SM_KEY_DBITS;
+                    int cols_in = n;
+                    if (GHOST) {
+                        const int x = x0 + j;
+                        cols_in = min(g.w - 1, x + half) - max(0, x - half) + 1;
+                    }
+                    wv[j] = sc ? (i32)(key[j] & ((1u << SM_KEY_DBITS) - 1u)) + 1 : g.D;
+                    bv[j] = sc ? (i32)sc - rows_in * cols_in : 0;
+                }
+                const size_t o = ((size_t)pair * g.h + y) * g.w + x0;
+                if (g.vec_ok && x0 + SM_P <= g.w) {
+                    int4 *pw = reinterpret_cast<int4 *>(web + o);
+                    pw[0] = make_int4(wv[0], wv[1], wv[2], wv[3]);
+                    pw[1] = make_int4(wv[4], wv[5], wv[6], wv[7]);
+                    if (best) {
+                        int4 *pb = reinterpret_cast<int4 *>(best + o);
+                        pb[0] = make_int4(bv[0], bv[1], bv[2], bv[3]);
+                        pb[1] = make_int4(bv[4], bv[5], bv[6], bv[7]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < SM_P; j++) {
+                        if (x0 + j < g.w) {
+                            web[o + j] = wv[j];
+                            if (best) best[o + j] = bv[j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// generic kernel: any window, any D.  One lane per pixel, direct window sums
+// from the ext image in global memory.  O(n * n/32) per matched shift.
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_match_wta_generic(const u32 *__restrict__ ext,
+                                                           i32 *__restrict__ web,
+                                                           i32 *__restrict__ best,
+                                                           const MatchGeom g, int ghost)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int pair = blockIdx.z;
+    if (x >= g.w) return;
+    const u32 *extL = ext + (size_t)pair * 2 * g.ext_image_words;
+    const u32 *extR = extL + g.ext_image_words;
+    const int half = g.half, n = g.n;
+
+    auto bit = [&](const u32 *img, int xx, int yy) -> u32 {
+        const int b = xx + g.pad_l;
+        return (img[(size_t)(yy + half) * g.ext_words + (b >> 5)] >> (b & 31)) & 1u;
+    };
+    auto word = [&](const u32 *img, int xx, int yy) -> u32 {   // 32 bits from xx
+        const int b = xx + g.pad_l;
+        const u32 *p = img + (size_t)(yy + half) * g.ext_words + (b >> 5);
+        return alignbit(p[1], p[0], b & 31);
+    };
+
+    // window extent; in ghost mode taps outside the image count 0
+    int xa = x - half, xb = x + half, ya = y - half, yb = y + half;
+    if (ghost) {
+        xa = max(xa, 0); xb = min(xb, g.w - 1);
+        ya = max(ya, 0); yb = min(yb, g.h - 1);
+    }
+
+    const u32 lc = bit(extL, x, y);
+    i32 bs = 0, bw = g.D;
+    for (int d = 0; d < g.D; d++) {
+        if (bit(extR, x + d, y) != lc) continue;   // no match at the pixel: score 0
+        i32 sum = 0;
+        for (int yy = ya; yy <= yb; yy++) {
+            for (int xs = xa; xs <= xb; xs += 32) {
+                const int cnt = min(32, xb - xs + 1);
+                u32 m = ~(word(extL, xs, yy) ^ word(extR, xs + d, yy));
+                if (cnt < 32) m &= (1u << cnt) - 1u;
+                sum += __builtin_popcount(m);
+            }
+        }
+        if (sum >= bs) { bs = sum; bw = d + 1; }
+    }
+    const size_t o = ((size_t)pair * g.h + y) * g.w + x;
+    web[o] = bw;
+    if (best) best[o] = bs;
+}
+
+// ---------------------------------------------------------------------------
+// host side: geometry and launch
+// ---------------------------------------------------------------------------
+
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+int sm_match_configure(sm_plan *plan)
+{
+    MatchGeom &g = plan->g;
+    const int W = plan->width, H = plan->height, D = plan->num_shifts;
+    g.w = W; g.h = H; g.D = D;
+    g.half = plan->square_width / 2;
+    g.n = 2 * g.half + 1;
+
+    int kernel;
+    if (D > (1 << SM_KEY_DBITS) || g.n > 25) kernel = SM_KERNEL_GENERIC;
+    else if (g.n <= 9) kernel = SM_KERNEL_A;
+    else if (g.n <= 16) kernel = SM_KERNEL_B;
+    else kernel = SM_KERNEL_C;
+    plan->kernel = kernel;
+
+    if (kernel == SM_KERNEL_GENERIC) {
+        g.pad_l = 32 * ceil_div(std::max(g.half, 1), 32);
+        // word() reads 2 words starting at bit x+d+pad_l with x <= W-1+half
+        g.ext_words = (g.pad_l + W + g.half + D + 31) / 32 + 2;
+        g.ext_rows = H + 2 * g.half;
+        g.ext_image_words = (long long)g.ext_words * g.ext_rows;
+        g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = 0;
+        g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = 0;
+        snprintf(plan->describe, sizeof plan->describe,
+                 "generic kernel (n=%d, D=%d): 1 lane/pixel, direct window sums", g.n, D);
+        return SM_OK;
+    }
+
+    g.pad_l = SM_PADT;
+    int nl = 1, log2nl = 0;
+    while (nl * SM_DSET < D) { nl <<= 1; log2nl++; }
+    g.nl = nl; g.log2nl = log2nl;
+    g.runs = nl == 1 ? 64 : (nl <= 8 ? 32 : 256 / nl);
+    g.threads = g.runs * nl;
+    g.tw = g.runs * SM_P;
+    g.tiles_x = ceil_div(W, g.tw);
+    g.plw = (SM_PADT + g.tw + g.half + 31) / 32 + 1;
+    g.prw = (SM_PADT + g.tw + g.half + nl * SM_DSET + 31) / 32 + 1;
+
+    // tile height: tall tiles amortise the n-1 warm-up rows, but the chip
+    // wants >= 2 waves on each of its 1024 SIMDs
+    const int waves_per_wg = std::max(1, g.threads / 64);
+    const int floor_h = g.n > 9 ? 32 : 16;
+    int th = 128;
+    for (; th > floor_h; th >>= 1) {
+        const long long waves = (long long)g.tiles_x * ceil_div(H, th) * waves_per_wg;
+        const int lds = (th + g.n - 1) * (g.plw + g.prw) * 3 * 4;
+        if (waves >= 2048 && lds <= 64 * 1024) break;
+    }
+    while ((th + g.n - 1) * (g.plw + g.prw) * 3 * 4 > 64 * 1024 && th > 1) th >>= 1;
+    th = std::min(th, std::max(1, H));
+    g.tile_h = th;
+    g.tiles_y = ceil_div(H, th);
+    g.nsr = th + g.n - 1;
+    g.lds_bytes = g.nsr * (g.plw + g.prw) * 3 * 4;
+    g.ext_words = (g.tiles_x - 1) * (g.tw / 32) + g.prw;
+    g.ext_rows = g.tiles_y * th + g.n - 1;
+    g.ext_image_words = (long long)g.ext_words * g.ext_rows;
+    g.vec_ok = (W % 4) == 0;
+
+    snprintf(plan->describe, sizeof plan->describe,
+             "tiled kernel %c (n=%d, D=%d, %s): tile %dx%d px, %d threads "
+             "(%d runs x %d shift-lanes), grid %dx%d, LDS %d B/wg, ext %dx%d words",
+             "ABC"[kernel], g.n, D, plan->border == SM_GHOST ? "ghost" : "toroidal",
+             g.tw, g.tile_h, g.threads, g.runs, g.nl, g.tiles_x, g.tiles_y, g.lds_bytes,
+             g.ext_words, g.ext_rows);
+    return SM_OK;
+}
+
+template <int MODE>
+static void launch_tiled(const sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
+{
+    const MatchGeom &g = plan->g;
+    const dim3 grid(g.tiles_x, g.tiles_y, pairs), block(g.threads);
+    const bool fulld = (g.D % SM_DSET) == 0 && g.nl * SM_DSET == g.D;
+    const bool ghost = plan->border == SM_GHOST;
+#define SM_GO(F, G) \
+    hipLaunchKernelGGL((k_match_wta<MODE, F, G>), grid, block, g.lds_bytes, st, plan->d_ext, d_web, d_best, g)
+    if (fulld) { if (ghost) SM_GO(true, true); else SM_GO(true, false); }
+    else       { if (ghost) SM_GO(false, true); else SM_GO(false, false); }
+#undef SM_GO
+}
+
+int sm_match_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
+{
+    const MatchGeom &g = plan->g;
+    switch (plan->kernel) {
+    case SM_KERNEL_A: launch_tiled<SM_KERNEL_A>(plan, pairs, d_web, d_best, st); break;
+    case SM_KERNEL_B: launch_tiled<SM_KERNEL_B>(plan, pairs, d_web, d_best, st); break;
+    case SM_KERNEL_C: launch_tiled<SM_KERNEL_C>(plan, pairs, d_web, d_best, st); break;
+    default: {
+        const dim3 grid(ceil_div(g.w, 256), g.h, pairs), block(256);
+        hipLaunchKernelGGL(k_match_wta_generic, grid, block, 0, st, plan->d_ext, d_web, d_best,
+                           g, plan->border == SM_GHOST ? 1 : 0);
+    }
+    }
+    SM_LAUNCH_CHECK("k_match_wta");
+    return SM_OK;
+}

@@ -1,0 +1,184 @@
+"""Host-side mirror of the reference's pipeline interface over the C ABI.
+
+The reference has no library API: `algorithm(first, second, width, height,
+AlgorithmParams)` (/root/reference/src/stereo.cu:289-347) calls its stage
+kernels in order.  `StereoPlan` exposes the same stages under the same names
+and argument meaning, each one a thin call into libstereo_hip.so.  torch is
+plumbing only: it owns the device buffers and the stream the launches go to.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import capi
+from .capi import BORDERS, check, lib
+
+# defaults of /root/reference/src/stereo.c:6-10
+NUM_SHIFTS = 30
+DEFAULT_THRESHOLD = 0.15
+DEFAULT_SQUARE_WIDTH = 21
+DEFAULT_TIMES = 32
+DEFAULT_LINES = 10
+
+
+@dataclass
+class AlgorithmParams:
+    """src/stereo.c:280-285"""
+    threshold: float = DEFAULT_THRESHOLD
+    square_width: int = DEFAULT_SQUARE_WIDTH
+    times: int = DEFAULT_TIMES
+    lines_to_draw: int = DEFAULT_LINES
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class StereoPlan:
+    """Geometry + device workspace for one image size / shift count / window."""
+
+    def __init__(self, width: int, height: int, num_shifts: int = NUM_SHIFTS,
+                 square_width: int = DEFAULT_SQUARE_WIDTH, border: str | int = "toroidal",
+                 max_pairs: int = 1, device: int = 0):
+        self.width, self.height = int(width), int(height)
+        self.num_shifts, self.square_width = int(num_shifts), int(square_width)
+        self.border = BORDERS[border] if isinstance(border, str) else int(border)
+        self.max_pairs, self.device = int(max_pairs), int(device)
+        self._h = C.c_void_p(0)
+        check(lib.sm_plan_create(self.device, self.width, self.height, self.num_shifts,
+                                 self.square_width, self.border, self.max_pairs,
+                                 C.byref(self._h)))
+        self._dev = torch.device("cuda", self.device)
+
+    def close(self):
+        if self._h:
+            lib.sm_plan_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers -----------------------------------------------------------
+    def describe(self) -> str:
+        return lib.sm_plan_describe(self._h).decode()
+
+    def workspace_bytes(self) -> int:
+        return int(lib.sm_plan_workspace_bytes(self._h))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+
+    def _images(self, t: torch.Tensor, dtype, name: str):
+        if t.device != self._dev or t.dtype != dtype or not t.is_contiguous():
+            raise ValueError(f"{name}: need a contiguous {dtype} tensor on {self._dev}, "
+                             f"got {t.dtype} on {t.device}")
+        if t.dim() == 2:
+            t = t.unsqueeze(0)
+        if t.dim() != 3 or t.shape[1] != self.height or t.shape[2] != self.width:
+            raise ValueError(f"{name}: shape {tuple(t.shape)} is not (pairs, {self.height}, {self.width})")
+        return t
+
+    def _new(self, pairs, dtype):
+        return torch.empty((pairs, self.height, self.width), dtype=dtype, device=self._dev)
+
+    # ---- step 1 ------------------------------------------------------------
+    def find_all_edges(self, left, right, threshold=DEFAULT_THRESHOLD, want_edges=True):
+        """find_all_edges x2 (src/stereo.cu:27-92,:312-313).  uint8 gray in; fills the
+        plan's packed edge workspace; returns the u8 {0,1} edge images if wanted."""
+        left = self._images(left, torch.uint8, "left")
+        right = self._images(right, torch.uint8, "right")
+        pairs = left.shape[0]
+        el = self._new(pairs, torch.uint8) if want_edges else None
+        er = self._new(pairs, torch.uint8) if want_edges else None
+        check(lib.sm_find_edges(self._h, _ptr(left), _ptr(right), float(threshold), pairs,
+                                _ptr(el), _ptr(er), self._stream()))
+        return (el, er) if want_edges else None
+
+    def load_edges(self, left_edges, right_edges):
+        """Start from u8 {0,1} edge images (the arguments of fillup_matches)."""
+        le = self._images(left_edges, torch.uint8, "left_edges")
+        re = self._images(right_edges, torch.uint8, "right_edges")
+        check(lib.sm_load_edges(self._h, _ptr(le), _ptr(re), le.shape[0], self._stream()))
+        return le.shape[0]
+
+    # ---- step 2: the hot path ----------------------------------------------
+    def match_wta(self, pairs=1, want_best=True, web=None, best=None):
+        """fillup_matches + fillup_scores + find_highest_scoring_shifts
+        (src/stereo.cu:127-225) in one launch -> (web, best)."""
+        web = self._new(pairs, torch.int32) if web is None else web
+        if want_best and best is None:
+            best = self._new(pairs, torch.int32)
+        check(lib.sm_match_wta(self._h, pairs, _ptr(web), _ptr(best if want_best else None),
+                               self._stream()))
+        return web, (best if want_best else None)
+
+    def run(self, left, right, threshold=DEFAULT_THRESHOLD, want_best=False, web=None, best=None):
+        """steps 1+2: uint8 pairs in, web (and optionally best) out."""
+        left = self._images(left, torch.uint8, "left")
+        right = self._images(right, torch.uint8, "right")
+        pairs = left.shape[0]
+        web = self._new(pairs, torch.int32) if web is None else web
+        if want_best and best is None:
+            best = self._new(pairs, torch.int32)
+        check(lib.sm_run(self._h, _ptr(left), _ptr(right), float(threshold), pairs, _ptr(web),
+                         _ptr(best if want_best else None), self._stream()))
+        return web, (best if want_best else None)
+
+    def debug_planes(self, pair: int, shift: int):
+        """matches-i, score_all-i, scores-i of the reference's debug build."""
+        m = torch.empty((self.height, self.width), dtype=torch.uint8, device=self._dev)
+        sa = torch.empty((self.height, self.width), dtype=torch.int32, device=self._dev)
+        sc = torch.empty_like(sa)
+        check(lib.sm_debug_planes(self._h, pair, shift, _ptr(m), _ptr(sa), _ptr(sc), self._stream()))
+        return m, sa, sc
+
+    # ---- step 3 ------------------------------------------------------------
+    def fill_web_holes(self, web, times=DEFAULT_TIMES):
+        """src/stereo.cu:235-256; returns the buffer the reference would return."""
+        web = self._images(web, torch.int32, "web").clone()
+        tmp = torch.empty_like(web)
+        which = C.c_int(0)
+        check(lib.sm_fill_web_holes(self._h, _ptr(web), _ptr(tmp), int(times), web.shape[0],
+                                    C.byref(which), self._stream()))
+        return tmp if which.value else web
+
+    def image_min_max(self, image):
+        image = self._images(image, torch.int32, "image")
+        mm = torch.empty((image.shape[0], 2), dtype=torch.int32, device=self._dev)
+        check(lib.sm_min_max(self._h, _ptr(image), image.shape[0], _ptr(mm), self._stream()))
+        return mm
+
+    def draw_contour_map(self, web, num_lines=DEFAULT_LINES):
+        """src/stereo.cu:261-285.  Raises StereoHipError(SM_ERR_ZERO_DIV) where the
+        reference would divide by zero."""
+        web = self._images(web, torch.int32, "web")
+        mm = self.image_min_max(web)
+        out = self._new(web.shape[0], torch.uint8)
+        check(lib.sm_draw_contour_map(self._h, _ptr(web), _ptr(mm), int(num_lines), web.shape[0],
+                                      _ptr(out), self._stream()))
+        check(lib.sm_plan_status(self._h, self._stream()))
+        return out
+
+    # ---- the whole of algorithm() --------------------------------------------
+    def algorithm(self, first, second, params: AlgorithmParams = AlgorithmParams(), step3=True):
+        """Stage order of src/stereo.cu:289-347; returns the images the reference dumps
+        (minus the per-shift planes: see debug_planes)."""
+        if params.square_width != self.square_width:
+            raise ValueError("params.square_width differs from the plan's")
+        el, er = self.find_all_edges(first, second, params.threshold)
+        web1, best = self.match_wta(el.shape[0], want_best=True)
+        res = {"edges-1": el, "edges-2": er, "score_best-0": best, "web-1": web1}
+        if step3:
+            web2 = self.fill_web_holes(web1, params.times)
+            res["web-2"] = web2
+            res["output-0"] = self.draw_contour_map(web2, params.lines_to_draw)
+        return res
+
+
+__all__ = ["AlgorithmParams", "StereoPlan", "capi"]

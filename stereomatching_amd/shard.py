@@ -1,0 +1,70 @@
+"""Batch sharding across the GPUs of a node.
+
+Stereo pairs are independent, so the hot path shards with NO data-path
+collective: pair j belongs to rank j mod world.  torch.distributed (backend
+"nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests) is used only for
+the barrier / max-over-ranks of the timing contract and, optionally, to
+collect the result maps on rank 0.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world) from the torchrun environment; (0, 0, 1) when absent."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
+            int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def init(backend: str | None = None):
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"),
+                                rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def pairs_for_rank(total_pairs: int, rank: int, world: int) -> list[int]:
+    """Indices of the pairs rank `rank` processes: j with j mod world == rank."""
+    return list(range(rank, total_pairs, world))
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(seconds: float, device="cpu") -> float:
+    if not dist.is_initialized():
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_maps(local: torch.Tensor, total_pairs: int, rank: int, world: int):
+    """Collect every rank's (pairs_r, H, W) int32 maps on rank 0 in pair order.
+    Ranks may hold different counts (total_pairs % world != 0), so the exchange is
+    an all_gather of equally padded blocks; returns (total_pairs, H, W) on rank 0,
+    None elsewhere."""
+    if world == 1:
+        return local
+    per = (total_pairs + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    blocks = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(blocks, pad)
+    if rank != 0:
+        return None
+    out = torch.empty((total_pairs,) + tuple(local.shape[1:]), dtype=local.dtype,
+                      device=local.device)
+    for r in range(world):
+        idx = pairs_for_rank(total_pairs, r, world)
+        out[idx] = blocks[r][: len(idx)]
+    return out

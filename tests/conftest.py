@@ -1,0 +1,36 @@
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def golden_cases():
+    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz"))
+
+
+def load_golden(name):
+    z = np.load(GOLDEN_DIR / f"{name}.npz")
+    thr, sw, times, lines, mode = z["params"]
+    params = dict(threshold=float(thr), square_width=int(sw), times=int(times),
+                  lines=int(lines), mode="ghost" if int(mode) else "toroidal")
+    return z, params
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The HIP layer on cuda:0.  Fails (not skips) if the extension is missing."""
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test run without a GPU"
+    from stereomatching_amd import pipeline
+    return pipeline

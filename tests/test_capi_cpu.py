@@ -1,0 +1,73 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every
+symbol include/stereo_hip.h declares, and rejects bad arguments before it
+touches a device (no compute calls: there is no GPU in the CPU suite)."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from stereomatching_amd import capi
+    syms = capi.declared_symbols()
+    assert len(syms) >= 20 and "sm_match_wta" in syms and "sm_plan_create" in syms
+    for s in syms:
+        assert hasattr(capi.lib, s), s
+        assert s in capi._SIGNATURES, f"{s} has no ctypes signature"
+    # and nothing is bound that the header does not declare
+    assert set(capi._SIGNATURES) == set(syms)
+
+
+def test_exported_symbols_are_plain_c():
+    out = subprocess.check_output(["nm", "-D", "--defined-only",
+                                   str(ROOT / "stereomatching_amd" / "libstereo_hip.so")], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    from stereomatching_amd import capi
+    assert set(capi.declared_symbols()) <= exported
+
+
+def test_argument_validation_precedes_device_use():
+    from stereomatching_amd import capi
+    h = C.c_void_p(0)
+    lib = capi.lib
+    # messages for the checks the reference's main() performs are the reference's own
+    # (/root/reference/src/stereo.c:382-385)
+    assert lib.sm_plan_create(0, 64, 48, 30, 65, 0, 1, C.byref(h)) == capi.SM_ERR_ARG
+    assert lib.sm_last_error() == b"error: square width must not be higher than image width/height"
+    assert lib.sm_plan_create(0, 64, 48, 30, 49, 0, 1, C.byref(h)) == capi.SM_ERR_ARG
+    assert lib.sm_plan_create(0, 0, 48, 30, 5, 0, 1, C.byref(h)) == capi.SM_ERR_ARG
+    assert lib.sm_plan_create(0, 64, 48, 0, 5, 0, 1, C.byref(h)) == capi.SM_ERR_ARG
+    assert lib.sm_plan_create(0, 64, 48, 70000, 5, 0, 1, C.byref(h)) == capi.SM_ERR_ARG
+    assert lib.sm_plan_create(0, 64, 48, 30, -1, 0, 1, C.byref(h)) == capi.SM_ERR_ARG
+    assert lib.sm_plan_create(0, 64, 48, 30, 5, 2, 1, C.byref(h)) == capi.SM_ERR_ARG
+    assert lib.sm_plan_create(0, 64, 48, 30, 5, 0, 0, C.byref(h)) == capi.SM_ERR_ARG
+    assert lib.sm_plan_create(0, 64, 48, 30, 5, 0, 1, None) == capi.SM_ERR_ARG
+    assert not h.value
+    assert lib.sm_match_wta(None, 1, None, None, None) == capi.SM_ERR_ARG
+    assert lib.sm_find_edges(None, None, None, 0.15, 1, None, None, None) == capi.SM_ERR_ARG
+    assert b"plan is NULL" in lib.sm_last_error()
+    assert lib.sm_plan_describe(None) == b""
+    lib.sm_plan_destroy(None)  # no-op
+
+
+def test_product_package_never_touches_the_oracle():
+    # the product path must not import, link or execute anything under oracle/
+    pkg = ROOT / "stereomatching_amd"
+    for p in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")) + \
+            list(pkg.rglob("*.c")):
+        text = p.read_text()
+        if p.name == "build.py":
+            continue  # builds the checker, does not use it
+        assert "liboracle" not in text and "stereo_oracle" not in text and \
+            "tests.oracle" not in text and "from tests" not in text, p
+
+
+def test_synth_and_pgm_roundtrip(tmp_path):
+    import numpy as np
+    from stereomatching_amd.synth import make_pair, read_pgm, write_pgm
+    a, b = make_pair(37, 21, 16, seed=3)
+    a2, b2 = make_pair(37, 21, 16, seed=3)
+    assert np.array_equal(a, a2) and np.array_equal(b, b2) and a.dtype == np.uint8
+    write_pgm(tmp_path / "x.pgm", a)
+    assert np.array_equal(read_pgm(tmp_path / "x.pgm"), a)

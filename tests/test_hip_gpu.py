@@ -1,0 +1,289 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle (tests/oracle.py) and the golden vectors of the compiled reference.
+Everything here is integer / byte work: the bar is bit-exact equality."""
+import numpy as np
+import pytest
+import torch
+
+from stereomatching_amd.synth import CONFIGS, make_pair
+from tests import oracle
+from tests.conftest import golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+PLANE_SHIFTS = (0, 1, 7, 29)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def rand_edges(w, h, seed, density=0.5):
+    rng = np.random.default_rng(seed)
+    return ((rng.random((h, w)) < density).astype(np.uint8),
+            (rng.random((h, w)) < density).astype(np.uint8))
+
+
+def hip_hot_path(hip, le, re, d, sw, mode, pairs=1):
+    h, w = le.shape[-2:]
+    plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
+    plan.load_edges(dev(le), dev(re))
+    web, best = plan.match_wta(pairs, want_best=True)
+    torch.cuda.synchronize()
+    desc = plan.describe()
+    plan.close()
+    return host(best), host(web), desc
+
+
+# ---------------------------------------------------------------------------
+# golden vectors of the compiled reference (D = 30)
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_pipeline_matches_reference_golden(hip, name):
+    z, p = load_golden(name)
+    h, w = z["left"].shape
+    plan = hip.StereoPlan(w, h, 30, p["square_width"], p["mode"])
+    res = plan.algorithm(dev(z["left"]), dev(z["right"]),
+                         hip.AlgorithmParams(p["threshold"], p["square_width"], p["times"], p["lines"]))
+    for k in ("edges-1", "edges-2", "score_best-0", "web-1", "web-2", "output-0"):
+        assert np.array_equal(host(res[k])[0], z[k]), (name, k, plan.describe())
+    for d in PLANE_SHIFTS:
+        m, sa, sc = plan.debug_planes(0, d)
+        assert np.array_equal(host(m), z[f"matches-{d}"]), (name, d)
+        assert np.array_equal(host(sa), z[f"score_all-{d}"]), (name, d)
+        assert np.array_equal(host(sc), z[f"scores-{d}"]), (name, d)
+    plan.close()
+
+
+# ---------------------------------------------------------------------------
+# hot path vs oracle: every kernel variant, ragged sizes, both borders
+# ---------------------------------------------------------------------------
+
+HOT_CASES = [
+    # (w, h, D, S)          kernel / what it exercises
+    (64, 48, 16, 5),        # A, one shift-lane
+    (71, 53, 30, 5),        # A, D not a multiple of 16, ragged width
+    (130, 70, 64, 7),       # A, 4 shift-lanes
+    (300, 150, 128, 9),     # A, the headline geometry, 2 tiles wide
+    (96, 64, 256, 9),       # A, 16 shift-lanes (DPP row_mirror)
+    (80, 40, 500, 3),       # A, 32 shift-lanes (cross-row shuffle), D > W
+    (64, 36, 1000, 1),      # A, 64 shift-lanes, 1x1 window
+    (90, 61, 64, 11),       # B
+    (77, 45, 30, 16),       # B, even S rounds up to 17 -> C
+    (100, 50, 48, 15),      # B upper end
+    (120, 80, 30, 21),      # C, the reference's default window
+    (70, 64, 128, 25),      # C upper end
+    (60, 50, 30, 27),       # generic (window too large for the tiled kernels)
+    (50, 40, 1100, 5),      # generic (D > 1024)
+    (9, 7, 16, 5),          # tiny
+    (8, 5, 3, 4),           # tiny, D < 16
+    (257, 129, 64, 7),      # one pixel past a tile in both directions
+    (33, 300, 16, 9),       # tall and narrow
+    (1024, 32, 64, 0),      # S = 0 -> 1x1 window
+]
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("w,h,d,sw", HOT_CASES)
+def test_hot_path_matches_oracle(hip, mode, w, h, d, sw):
+    le, re = rand_edges(w, h, seed=w * 7 + h * 3 + d + sw)
+    best, web, desc = hip_hot_path(hip, le, re, d, sw, mode)
+    obest, oweb = oracle.hot_path(le, re, d, sw, mode)
+    assert np.array_equal(web[0], oweb), desc
+    assert np.array_equal(best[0], obest), desc
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("kind", ["zeros", "ones", "left_only", "sparse"])
+def test_hot_path_degenerate_edges(hip, mode, kind):
+    w, h, d, sw = 100, 60, 30, 9
+    le = np.zeros((h, w), np.uint8)
+    re = np.zeros((h, w), np.uint8)
+    if kind == "ones":
+        le[:] = 1; re[:] = 1
+    elif kind == "left_only":       # no pixel ever matches in toroidal mode -> web = D, best = 0
+        le[:] = 1
+    elif kind == "sparse":
+        le[::7, ::5] = 1; re[::7, 3::5] = 1
+    best, web, desc = hip_hot_path(hip, le, re, d, sw, mode)
+    obest, oweb = oracle.hot_path(le, re, d, sw, mode)
+    assert np.array_equal(web[0], oweb), desc
+    assert np.array_equal(best[0], obest), desc
+    if kind == "left_only" and mode == "toroidal":
+        assert (web == d).all() and (best == 0).all()
+
+
+def test_batch_of_pairs_equals_single_runs(hip):
+    w, h, d, sw, pairs = 140, 90, 64, 7, 5
+    les, res = zip(*[rand_edges(w, h, seed=100 + i, density=0.3) for i in range(pairs)])
+    le, re = np.stack(les), np.stack(res)
+    best, web, _ = hip_hot_path(hip, le, re, d, sw, "toroidal", pairs=pairs)
+    for i in range(pairs):
+        ob, ow = oracle.hot_path(le[i], re[i], d, sw, "toroidal")
+        assert np.array_equal(web[i], ow) and np.array_equal(best[i], ob), i
+
+
+def test_web_only_output_and_errors(hip):
+    w, h = 64, 40
+    plan = hip.StereoPlan(w, h, 30, 5)
+    with pytest.raises(hip.capi.StereoHipError, match="edges of only 0 are loaded"):
+        plan.match_wta(1)
+    le, re = rand_edges(w, h, 1)
+    plan.load_edges(dev(le), dev(re))
+    web, best = plan.match_wta(1, want_best=False)
+    assert best is None
+    assert np.array_equal(host(web)[0], oracle.hot_path(le, re, 30, 5)[1])
+    with pytest.raises(hip.capi.StereoHipError, match="pairs 2 outside"):
+        plan.match_wta(2)
+    with pytest.raises(ValueError):
+        plan.load_edges(dev(le[:10]), dev(re[:10]))
+    with pytest.raises(hip.capi.StereoHipError, match="threshold must be between 0 and 1"):
+        plan.find_all_edges(dev(le), dev(re), 1.5)
+    plan.close()
+
+
+# ---------------------------------------------------------------------------
+# step 1: edges
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("thr", [0.0, 0.05, 0.15, 0.25, 0.5, 0.75, 1.0, 1.0 / 3.0, 0.1])
+def test_edge_decision_exhaustive(hip, thr):
+    """every pair of in-image side sums: device arithmetic == host arithmetic"""
+    import ctypes as C
+    tab = torch.empty((766, 766), dtype=torch.uint8, device="cuda")
+    hip.capi.check(hip.capi.lib.sm_debug_edge_table(0, thr, C.c_void_p(tab.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(host(tab), oracle.edge_table(thr))
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("w,h,kind,thr", [
+    (64, 48, "scene", 0.15), (301, 97, "scene", 0.15), (130, 77, "noise", 0.5),
+    (40, 40, "noise", 0.0), (55, 33, "scene", 1.0), (3, 3, "noise", 0.15),
+    (1, 9, "noise", 0.15), (9, 1, "noise", 0.15), (2, 2, "noise", 0.3), (512, 64, "constant", 0.15)])
+def test_edges_match_oracle(hip, mode, w, h, kind, thr):
+    left, right = make_pair(w, h, 16, seed=w + h, kind=kind)
+    sw = min(5, w, h)
+    plan = hip.StereoPlan(w, h, 16, sw, mode)
+    el, er = plan.find_all_edges(dev(left), dev(right), thr)
+    assert np.array_equal(host(el)[0], oracle.find_all_edges(left, thr, mode))
+    assert np.array_equal(host(er)[0], oracle.find_all_edges(right, thr, mode))
+    # and the packed copy the hot path consumes agrees with the u8 one
+    web, best = plan.match_wta(1)
+    ob, ow = oracle.hot_path(host(el)[0], host(er)[0], 16, sw, mode)
+    assert np.array_equal(host(web)[0], ow) and np.array_equal(host(best)[0], ob)
+    plan.close()
+
+
+# ---------------------------------------------------------------------------
+# step 3
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("times", [0, 1, 2, 5, 32])
+def test_fill_web_holes(hip, times):
+    rng = np.random.default_rng(times)
+    web = rng.integers(1, 31, (2, 37, 53)).astype(np.int32)
+    web[rng.random(web.shape) < 0.2] = 0
+    web[:, 0, :5] = 0
+    web[:, -1, -5:] = 0       # first/last rows: flat-index neighbours leave the array
+    plan = hip.StereoPlan(53, 37, 30, 5, max_pairs=2)
+    got = host(plan.fill_web_holes(dev(web), times))
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.fill_web_holes(web[i], times)), (times, i)
+    # no zeros -> identity
+    full = np.maximum(web, 1)
+    assert np.array_equal(host(plan.fill_web_holes(dev(full), times)), full)
+    plan.close()
+
+
+def test_min_max_and_contour(hip):
+    rng = np.random.default_rng(3)
+    web = rng.integers(1, 129, (3, 45, 70)).astype(np.int32)
+    web[2] = 7                                  # constant image: zero interval
+    plan = hip.StereoPlan(70, 45, 128, 5, max_pairs=3)
+    mm = host(plan.image_min_max(dev(web)))
+    assert np.array_equal(mm[:, 0], web.reshape(3, -1).min(1))
+    assert np.array_equal(mm[:, 1], web.reshape(3, -1).max(1))
+    for lines in (1, 3, 10, 127):
+        out = host(plan.draw_contour_map(dev(web[:2]), lines))
+        for i in range(2):
+            assert np.array_equal(out[i], oracle.draw_contour_map(web[i], lines)), (lines, i)
+    with pytest.raises(hip.capi.StereoHipError) as e:
+        plan.draw_contour_map(dev(web), 10)
+    assert e.value.code == hip.capi.SM_ERR_ZERO_DIV
+    with pytest.raises(hip.capi.StereoHipError):
+        plan.draw_contour_map(dev(web[:2]), 0)
+    # the flag is cleared by the status call
+    plan.draw_contour_map(dev(web[:2]), 10)
+    plan.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configurations
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("cfg", ["C1", "C2"])
+def test_baseline_config_full_size_vs_oracle(hip, cfg):
+    w, h, d, sw, mode = CONFIGS[cfg]
+    left, right = make_pair(w, h, d, seed=1)
+    plan = hip.StereoPlan(w, h, d, sw, mode)
+    el, er = plan.find_all_edges(dev(left), dev(right), 0.15)
+    web, best = plan.match_wta(1)
+    oel = oracle.find_all_edges(left, 0.15, mode)
+    oer = oracle.find_all_edges(right, 0.15, mode)
+    assert np.array_equal(host(el)[0], oel) and np.array_equal(host(er)[0], oer)
+    ob, ow = oracle.hot_path(oel, oer, d, sw, mode)
+    assert np.array_equal(host(web)[0], ow), plan.describe()
+    assert np.array_equal(host(best)[0], ob)
+    plan.close()
+
+
+@pytest.mark.parametrize("cfg", ["C3", "C5"])
+def test_baseline_config_full_size_properties(hip, cfg):
+    """4K configurations: too big for the CPU oracle in seconds, so check (a) bands
+    of the full-size result against the oracle run on the same rows (the result at
+    a pixel depends only on rows within the window), (b) range / consistency
+    invariants, (c) toroidal shift-equivariance."""
+    w, h, d, sw, mode = CONFIGS[cfg]
+    half = sw // 2
+    left, right = make_pair(w, h, d, seed=2)
+    plan = hip.StereoPlan(w, h, d, sw, mode)
+    el, er = plan.find_all_edges(dev(left), dev(right), 0.15)
+    web, best = plan.match_wta(1)
+    web_h, best_h, el_h, er_h = host(web)[0], host(best)[0], host(el)[0], host(er)[0]
+
+    # (a) bands of full-width rows: every window of rows [y0, y1) lies inside the
+    # crop [y0-half, y1+half), so the crop's own borders never reach them.  In
+    # ghost mode the image's top and bottom rows are real borders of the crop too;
+    # in toroidal mode they would wrap differently and are covered by (c).
+    bands = [(h // 2 - 7, h // 2 + 17)]
+    if mode == "ghost":
+        bands += [(0, 24), (h - 24, h)]
+    for y0, y1 in bands:
+        a, b = max(0, y0 - half), min(h, y1 + half)
+        ob, ow = oracle.hot_path(el_h[a:b], er_h[a:b], d, sw, mode)
+        lo = y0 - a
+        assert np.array_equal(web_h[y0:y1], ow[lo:lo + y1 - y0]), (cfg, y0, plan.describe())
+        assert np.array_equal(best_h[y0:y1], ob[lo:lo + y1 - y0]), (cfg, y0)
+    e_rows = slice(h // 3, h // 3 + 16)
+    crop = slice(h // 3 - 1, h // 3 + 17)
+    assert np.array_equal(el_h[e_rows], oracle.find_all_edges(left[crop], 0.15, mode)[1:-1])
+
+    # (b) invariants
+    n = 2 * half + 1
+    assert web_h.min() >= 1 and web_h.max() <= d
+    assert best_h.min() >= 0 and best_h.max() <= n * n
+    assert ((best_h == 0) <= (web_h == d)).all()
+
+    # (c) toroidal: rolling both inputs rolls the outputs
+    if mode == "toroidal":
+        sx, sy = 1237, 411
+        l2 = np.roll(left, (sy, sx), (0, 1)); r2 = np.roll(right, (sy, sx), (0, 1))
+        web2, best2 = plan.run(dev(l2), dev(r2), 0.15, want_best=True)
+        assert np.array_equal(host(web2)[0], np.roll(web_h, (sy, sx), (0, 1)))
+        assert np.array_equal(host(best2)[0], np.roll(best_h, (sy, sx), (0, 1)))
+    plan.close()

@@ -1,0 +1,117 @@
+"""CPU tests of the checker itself: the C restatement against the golden
+vectors produced by the compiled reference, against the compiled reference
+directly (where oracle/_ref exists), and its two window-sum variants against
+each other."""
+import numpy as np
+import pytest
+
+from stereomatching_amd.synth import make_pair
+from tests import oracle
+from tests.conftest import golden_cases, load_golden
+
+PLANE_SHIFTS = (0, 1, 7, 29)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+@pytest.mark.parametrize("faithful", [True, False])
+def test_oracle_matches_golden(name, faithful):
+    z, p = load_golden(name)
+    got = oracle.pipeline(z["left"], z["right"], p["threshold"], oracle.REF_NUM_SHIFTS,
+                          p["square_width"], p["times"], p["lines"], p["mode"], faithful)
+    for k in ("edges-1", "edges-2", "score_best-0", "web-1", "web-2", "output-0"):
+        assert np.array_equal(got[k], z[k]), (name, k)
+    for d in PLANE_SHIFTS:
+        m = oracle.match_plane(got["edges-1"], got["edges-2"], d, p["mode"])
+        assert np.array_equal(m, z[f"matches-{d}"]), (name, d)
+        sa = oracle.addup(m, p["square_width"], p["mode"], faithful)
+        assert np.array_equal(sa, z[f"score_all-{d}"]), (name, d)
+        assert np.array_equal(oracle.record_score(m, sa), z[f"scores-{d}"]), (name, d)
+
+
+@pytest.mark.skipif(not oracle.ref_available(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("w,h,sw,kind,thr", [
+    (72, 41, 7, "scene", 0.15), (41, 72, 11, "noise", 0.5), (30, 30, 30, "scene", 0.0),
+    (64, 32, 0, "scene", 1.0), (45, 52, 1, "scene", 0.15)])
+def test_oracle_matches_compiled_reference(mode, w, h, sw, kind, thr):
+    left, right = make_pair(w, h, 30, seed=w * 131 + h, kind=kind)
+    try:
+        ref = oracle.run_reference(left, right, thr, sw, 6, 3, mode)
+    except RuntimeError as e:
+        # SIGFPE: the reference divided by a zero contour interval; the
+        # restatement must report the same condition
+        assert "exited -8" in str(e)
+        with pytest.raises(ZeroDivisionError):
+            oracle.pipeline(left, right, thr, 30, sw, 6, 3, mode, faithful=True)
+        return
+    got = oracle.pipeline(left, right, thr, 30, sw, 6, 3, mode, faithful=True)
+    for k, v in got.items():
+        assert np.array_equal(v, ref[k]), k
+    for d in range(30):
+        m = oracle.match_plane(got["edges-1"], got["edges-2"], d, mode)
+        assert np.array_equal(m, ref[f"matches-{d}"])
+        sa = oracle.addup(m, sw, mode, True)
+        assert np.array_equal(sa, ref[f"score_all-{d}"])
+        assert np.array_equal(oracle.record_score(m, sa), ref[f"scores-{d}"])
+
+
+@pytest.mark.skipif(not oracle.ref_available(), reason="oracle/_ref not built")
+def test_constant_image_ties_go_to_last_shift():
+    # all scores equal -> the reference's second sweep leaves the LAST shift
+    left, right = make_pair(40, 30, 30, kind="constant")
+    ref = oracle.run_reference(left, right, 0.15, 5, 0, 10, "toroidal",
+                               keep=lambda s: s in ("web-1", "score_best-0"), allow_sigfpe=True)
+    assert ref["returncode"] == -8     # constant web -> zero contour interval -> SIGFPE
+    best, web = oracle.hot_path(np.zeros((30, 40), np.uint8), np.zeros((30, 40), np.uint8), 30, 5)
+    assert np.array_equal(web, ref["web-1"]) and (web == 30).all()
+    assert np.array_equal(best, ref["score_best-0"]) and (best == 25).all()
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("d,sw", [(16, 5), (64, 7), (128, 9), (37, 12), (256, 11)])
+def test_fast_and_faithful_window_sums_agree(mode, d, sw):
+    rng = np.random.default_rng(d * 7 + sw)
+    le = rng.integers(0, 2, (40, 90), dtype=np.uint8)
+    re = rng.integers(0, 2, (40, 90), dtype=np.uint8)
+    b1, w1 = oracle.hot_path(le, re, d, sw, mode, faithful=True)
+    b2, w2 = oracle.hot_path(le, re, d, sw, mode, faithful=False)
+    assert np.array_equal(b1, b2) and np.array_equal(w1, w2)
+    assert w1.min() >= 1 and w1.max() <= d
+
+
+def test_edge_decision_is_a_function_of_the_side_sums():
+    # the integer-keyed form used to pin the GPU arithmetic must agree with the
+    # image-level restatement
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (24, 31), dtype=np.uint8)
+    for thr in (0.0, 0.15, 0.5, 1.0):
+        e = oracle.find_all_edges(img, thr, "toroidal")
+        p = np.pad(img.astype(np.int64), 1, mode="wrap")
+        H, W = img.shape
+        v = lambda dy, dx: p[1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+        sides = [
+            (v(-1, -1) + v(0, -1) + v(1, -1), v(-1, 1) + v(0, 1) + v(1, 1)),
+            (v(-1, -1) + v(-1, 0) + v(-1, 1), v(1, -1) + v(1, 0) + v(1, 1)),
+            (v(-1, -1) + v(-1, 0) + v(0, -1), v(0, 1) + v(1, 0) + v(1, 1)),
+            (v(1, -1) + v(1, 0) + v(0, -1), v(-1, 0) + v(-1, 1) + v(0, 1)),
+        ]
+        want = np.zeros_like(e)
+        for a, b in sides:
+            for y in range(H):
+                for x in range(W):
+                    want[y, x] |= oracle.edge_decision(a[y, x], b[y, x], thr)
+        assert np.array_equal(e, want), thr
+
+
+def test_fill_web_holes_and_contour_semantics():
+    web = np.array([[3, 0, 5, 2], [0, 7, 0, 1], [4, 4, 0, 9]], np.int32)
+    # one observable sweep for times=2 (the reference returns the buffer it READ last)
+    assert np.array_equal(oracle.fill_web_holes(web, 0), web)
+    got1 = oracle.fill_web_holes(web, 1)
+    assert np.array_equal(got1, web)          # the only sweep's output is discarded
+    got2 = oracle.fill_web_holes(web, 2)
+    assert got2[0, 1] == (5 + 7 + 3 + 0) // 4 and got2[1, 0] == (7 + 4 + 2 + 3) // 4
+    with pytest.raises(ZeroDivisionError):
+        oracle.draw_contour_map(np.full((4, 4), 3, np.int32), 10)
+    out = oracle.draw_contour_map(np.arange(1, 31, dtype=np.int32).reshape(5, 6), 10)
+    assert out.dtype == np.uint8 and out.sum() > 0
