@@ -45,6 +45,9 @@
 #include "sm_internal.h"
 
 #include <algorithm>
+#include <stdlib.h>
+
+static_assert(SM_DSET == 16 && SM_P == 8, "pixel_winner / the key loop are written out for 16 x 8");
 
 // ---------------------------------------------------------------------------
 // small device helpers
@@ -69,28 +72,83 @@ __device__ __forceinline__ u32 ubfe(u32 v, u32 off, u32 width)
 {
     return __builtin_amdgcn_ubfe(v, off, width);
 }
-__device__ __forceinline__ u32 sbfe1(u32 v, u32 off)
-{
-    return (u32)__builtin_amdgcn_sbfe((int)v, off, 1);   // 0 or 0xffffffff
-}
-
 template <int CTRL>
-__device__ __forceinline__ u32 dpp_max(u32 v)
+__device__ __forceinline__ i32 dpp_max(i32 v)
 {
-    u32 o = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    i32 o = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
     return v > o ? v : o;
 }
 
-// all-reduce max over groups of nl adjacent lanes (nl uniform, power of two)
-__device__ __forceinline__ u32 group_max(u32 v, int nl)
+// all-reduce max of P keys over groups of nl adjacent lanes (nl uniform,
+// power of two): one uniform branch per level, not per key
+__device__ __forceinline__ void group_max(i32 (&v)[SM_P], int nl)
 {
-    if (nl >= 2) v = dpp_max<0xB1>(v);    // quad_perm [1,0,3,2]
-    if (nl >= 4) v = dpp_max<0x4E>(v);    // quad_perm [2,3,0,1]
-    if (nl >= 8) v = dpp_max<0x141>(v);   // row_half_mirror
-    if (nl >= 16) v = dpp_max<0x140>(v);  // row_mirror
-    if (nl >= 32) { u32 o = (u32)__shfl_xor((int)v, 16); v = v > o ? v : o; }
-    if (nl >= 64) { u32 o = (u32)__shfl_xor((int)v, 32); v = v > o ? v : o; }
-    return v;
+    if (nl < 2) return;
+#pragma unroll
+    for (int j = 0; j < SM_P; j++) v[j] = dpp_max<0xB1>(v[j]);    // quad_perm [1,0,3,2]
+    if (nl < 4) return;
+#pragma unroll
+    for (int j = 0; j < SM_P; j++) v[j] = dpp_max<0x4E>(v[j]);    // quad_perm [2,3,0,1]
+    if (nl < 8) return;
+#pragma unroll
+    for (int j = 0; j < SM_P; j++) v[j] = dpp_max<0x141>(v[j]);   // row_half_mirror
+    if (nl < 16) return;
+#pragma unroll
+    for (int j = 0; j < SM_P; j++) v[j] = dpp_max<0x140>(v[j]);   // row_mirror
+    if (nl < 32) return;
+#pragma unroll
+    for (int j = 0; j < SM_P; j++) { i32 o = __shfl_xor(v[j], 16); v[j] = v[j] > o ? v[j] : o; }
+    if (nl < 64) return;
+#pragma unroll
+    for (int j = 0; j < SM_P; j++) { i32 o = __shfl_xor(v[j], 32); v[j] = v[j] > o ? v[j] : o; }
+}
+
+// Measured issue rates on gfx950 (tools/ubench_valu*.hip): v_and/or/xor/add/
+// sub/lshr/ashr/bitop3 retire a wave64 in ~2 cycles, but v_bfe/bcnt/alignbit/
+// max/max3/lshl/lshl_or/mad/cmp take ~4.  The winner search is written for that:
+// the centre-match bit of the candidate is kept in the SIGN bit of r (one slow
+// left shift per pixel, then r += r per candidate, a full-rate op), an
+// unmatched candidate gets the sign bit forced on (one bitop3) and the keys
+// are compared as signed ints, so unmatched < every matched key.
+//   per candidate: v_lshl_or (slow) + v_bitop3 + v_add (fast) + half a v_max3_i32
+__device__ __forceinline__ i32 imax(i32 a, i32 b) { return a > b ? a : b; }
+
+// (x << 10) | dd as ONE v_lshl_or_b32, and x + x as a v_add_u32: left to
+// itself hipcc emits v_lshlrev + an extra v_bitop3 for the first and a
+// (half-rate) v_lshlrev for the second.
+template <int DD>
+__device__ __forceinline__ u32 make_key(u32 a)
+{
+    u32 k;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(k) : "v"(a), "n"(SM_KEY_DBITS), "n"(DD));
+    return k;
+}
+__device__ __forceinline__ u32 twice(u32 r)
+{
+    u32 o;
+    asm("v_add_u32 %0, %1, %1" : "=v"(o) : "v"(r));
+    return o;
+}
+
+template <int J, bool FULLD>
+__device__ __forceinline__ i32 pixel_winner(const u32 (&A)[SM_DSET][SM_P], u32 lc, u32 rc, u32 vb)
+{
+    // bit (J+dd) of rj = centre match of pixel J at shift d0+dd
+    u32 rj = ~(rc ^ (u32)__builtin_amdgcn_sbfe((int)lc, J, 1));
+    if (!FULLD) rj &= vb << J;
+    u32 r = rj << (31 - (J + SM_DSET - 1));     // candidate dd = 15 in the sign bit
+    i32 k = (i32)0x80000000u;
+#define SM_CAND(DD, R) (i32)(make_key<DD>(A[DD][J]) | (~(R) & 0x80000000u))
+#define SM_PAIR(HI)                                                             \
+    {                                                                           \
+        const u32 r1 = twice(r);                                                \
+        k = imax(imax(SM_CAND(HI, r), SM_CAND(HI - 1, r1)), k);                 \
+        r = twice(r1);                                                          \
+    }
+    SM_PAIR(15) SM_PAIR(13) SM_PAIR(11) SM_PAIR(9) SM_PAIR(7) SM_PAIR(5) SM_PAIR(3) SM_PAIR(1)
+#undef SM_PAIR
+#undef SM_CAND
+    return k;
 }
 
 // ---------------------------------------------------------------------------
@@ -164,6 +222,11 @@ __global__ __launch_bounds__(256) void k_match_wta(const u32 *__restrict__ ext,
 
     // masks for the window extraction
     const u32 w2n = 2u * (u32)n;
+    u32 mask_a[SM_P];                     // MODE A: 2n bits from bit 2j (wave-uniform)
+    if (MODE == SM_KERNEL_A) {
+#pragma unroll
+        for (int j = 0; j < SM_P; j++) mask_a[j] = ((w2n >= 32 ? 0u : (1u << w2n)) - 1u) << (2 * j);
+    }
     u32 mask_b = 0;                       // MODE B: low 2n bits
     u32 mask_c[SM_P];                     // MODE C: low 2j+2n-32 bits of Z1
     if (MODE == SM_KERNEL_B)
@@ -251,7 +314,7 @@ __global__ __launch_bounds__(256) void k_match_wta(const u32 *__restrict__ ext,
 #pragma unroll
             for (int j = 0; j < SM_P; j++) {
                 if (MODE == SM_KERNEL_A) {
-                    A[dd][j] += __builtin_popcount(ubfe(z[0], 2 * j, w2n));
+                    A[dd][j] += __builtin_popcount(z[0] & mask_a[j]);   // v_and (fast) + v_bcnt
                 } else if (MODE == SM_KERNEL_B) {
                     const u32 t = j ? alignbit(z[ZW - 1], z[0], 2 * j) : z[0];
                     A[dd][j] += __builtin_popcount(t & mask_b);
@@ -271,20 +334,17 @@ __global__ __launch_bounds__(256) void k_match_wta(const u32 *__restrict__ ext,
             const u32 lc = alignbit(rowLc[1], rowLc[0], shLc);
             const u32 rc = alignbit(rowRc[1], rowRc[0], shRc);
 
-            u32 key[SM_P];
-#pragma unroll
-            for (int j = 0; j < SM_P; j++) {
-                // bit (j+dd) of rj = centre match of pixel j at shift d0+dd
-                u32 rj = ~(rc ^ sbfe1(lc, j));
-                if (!FULLD) rj &= vb << j;
-                u32 k = 0;
-#pragma unroll
-                for (int dd = 0; dd < SM_DSET; dd++) {
-                    const u32 cand = ((A[dd][j] << SM_KEY_DBITS) | (u32)dd) & sbfe1(rj, j + dd);
-                    k = k > cand ? k : cand;
-                }
-                key[j] = group_max(k + (u32)d0, g.nl);
-            }
+            // signed keys: negative = no shift of this lane matched
+            i32 key[SM_P];
+            key[0] = pixel_winner<0, FULLD>(A, lc, rc, vb) + d0;
+            key[1] = pixel_winner<1, FULLD>(A, lc, rc, vb) + d0;
+            key[2] = pixel_winner<2, FULLD>(A, lc, rc, vb) + d0;
+            key[3] = pixel_winner<3, FULLD>(A, lc, rc, vb) + d0;
+            key[4] = pixel_winner<4, FULLD>(A, lc, rc, vb) + d0;
+            key[5] = pixel_winner<5, FULLD>(A, lc, rc, vb) + d0;
+            key[6] = pixel_winner<6, FULLD>(A, lc, rc, vb) + d0;
+            key[7] = pixel_winner<7, FULLD>(A, lc, rc, vb) + d0;
+            group_max(key, g.nl);
 
             if (s == 0 && x0 < g.w) {
                 // bias carried by every A of pixel j at row t
@@ -296,13 +356,14 @@ __global__ __launch_bounds__(256) void k_match_wta(const u32 *__restrict__ ext,
                 i32 wv[SM_P], bv[SM_P];
 #pragma unroll
                 for (int j = 0; j < SM_P; j++) {
-                    const u32 sc = key[j] >> SM_KEY_DBITS;
+                    // a matched shift always scores >= 1 (its own pixel is in the window)
+                    const u32 sc = key[j] < 0 ? 0u : (u32)key[j] >> SM_KEY_DBITS;
                     int cols_in = n;
                     if (GHOST) {
                         const int x = x0 + j;
                         cols_in = min(g.w - 1, x + half) - max(0, x - half) + 1;
                     }
-                    wv[j] = sc ? (i32)(key[j] & ((1u << SM_KEY_DBITS) - 1u)) + 1 : g.D;
+                    wv[j] = sc ? (i32)((u32)key[j] & ((1u << SM_KEY_DBITS) - 1u)) + 1 : g.D;
                     bv[j] = sc ? (i32)sc - rows_in * cols_in : 0;
                 }
                 const size_t o = ((size_t)pair * g.h + y) * g.w + x0;
@@ -345,7 +406,7 @@ __global__ __launch_bounds__(256) void k_match_wta_generic(const u32 *__restrict
     if (x >= g.w) return;
     const u32 *extL = ext + (size_t)pair * 2 * g.ext_image_words;
     const u32 *extR = extL + g.ext_image_words;
-    const int half = g.half, n = g.n;
+    const int half = g.half;
 
     auto bit = [&](const u32 *img, int xx, int yy) -> u32 {
         const int b = xx + g.pad_l;
@@ -390,6 +451,21 @@ __global__ __launch_bounds__(256) void k_match_wta_generic(const u32 *__restrict
 
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+static bool tiled_fulld(const MatchGeom &g) { return g.nl * SM_DSET == g.D; }
+
+static const void *tiled_kernel_ptr(int mode, bool fulld, bool ghost)
+{
+#define SM_ROW(M)                                                                       \
+    fulld ? (ghost ? (const void *)k_match_wta<M, true, true> : (const void *)k_match_wta<M, true, false>) \
+          : (ghost ? (const void *)k_match_wta<M, false, true> : (const void *)k_match_wta<M, false, false>)
+    switch (mode) {
+    case SM_KERNEL_A: return SM_ROW(SM_KERNEL_A);
+    case SM_KERNEL_B: return SM_ROW(SM_KERNEL_B);
+    default: return SM_ROW(SM_KERNEL_C);
+    }
+#undef SM_ROW
+}
+
 int sm_match_configure(sm_plan *plan)
 {
     MatchGeom &g = plan->g;
@@ -429,18 +505,45 @@ int sm_match_configure(sm_plan *plan)
     g.plw = (SM_PADT + g.tw + g.half + 31) / 32 + 1;
     g.prw = (SM_PADT + g.tw + g.half + nl * SM_DSET + 31) / 32 + 1;
 
-    // tile height: tall tiles amortise the n-1 warm-up rows, but the chip
-    // wants >= 2 waves on each of its 1024 SIMDs
-    const int waves_per_wg = std::max(1, g.threads / 64);
-    const int floor_h = g.n > 9 ? 32 : 16;
-    int th = 128;
-    for (; th > floor_h; th >>= 1) {
-        const long long waves = (long long)g.tiles_x * ceil_div(H, th) * waves_per_wg;
-        const int lds = (th + g.n - 1) * (g.plw + g.prw) * 3 * 4;
-        if (waves >= 2048 && lds <= 64 * 1024) break;
+    // ---- tile height.  Tall tiles amortise the n-1 warm-up rows, but the grid
+    // should fill the chip's resident slots in whole rounds: a tail round with a
+    // third of the CUs busy costs as much as a full one.  Model: a workgroup
+    // puts threads/256 waves on each SIMD; a SIMD issues one wave-instruction
+    // per 2 cycles, a single wave at most one per 4; rounds run back to back.
+    int cus = 256, th_env = 0;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        if (const char *e = getenv("SM_TILE_H")) th_env = atoi(e);   // tuning / tests only
     }
-    while ((th + g.n - 1) * (g.plw + g.prw) * 3 * 4 > 64 * 1024 && th > 1) th >>= 1;
-    th = std::min(th, std::max(1, H));
+    const void *kfn = tiled_kernel_ptr(kernel, tiled_fulld(g), plan->border == SM_GHOST);
+    const double wps = g.threads / 256.0;            // waves per SIMD per workgroup
+    const double warm = 0.4 * (g.n - 1) + 2.0;       // warm-up rows cost ~0.4 of an output row
+    auto lds_of = [&](int th) { return (th + g.n - 1) * (g.plw + g.prw) * 3 * 4; };
+    int th = 0;
+    double best_cost = 0;
+    for (int c = 4; c <= 256; c++) {
+        if (c > H && c != 4) break;
+        const int cand = std::min(c, H);
+        if (lds_of(cand) > 64 * 1024) break;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, g.threads, lds_of(cand)) != hipSuccess
+            || per_cu < 1)
+            per_cu = 1;
+        const long long tiles = (long long)g.tiles_x * ceil_div(H, cand) * plan->max_pairs;
+        const long long slots = (long long)cus * per_cu;
+        double cost = 0;
+        for (long long left = tiles; left > 0; left -= slots) {
+            const long long m = std::min(left, slots);
+            const double k = (double)((m + cus - 1) / cus) * wps;   // waves per SIMD this round
+            cost += (cand + warm) * std::max(4.0, 2.0 * k);
+        }
+        if (th == 0 || cost < best_cost * 0.999) { th = cand; best_cost = cost; }
+    }
+    if (th == 0) th = 1;
+    if (th_env > 0) th = std::min(th_env, H);
+    while (lds_of(th) > 64 * 1024 && th > 1) th--;
     g.tile_h = th;
     g.tiles_y = ceil_div(H, th);
     g.nsr = th + g.n - 1;
@@ -464,7 +567,7 @@ static void launch_tiled(const sm_plan *plan, int pairs, i32 *d_web, i32 *d_best
 {
     const MatchGeom &g = plan->g;
     const dim3 grid(g.tiles_x, g.tiles_y, pairs), block(g.threads);
-    const bool fulld = (g.D % SM_DSET) == 0 && g.nl * SM_DSET == g.D;
+    const bool fulld = tiled_fulld(g);
     const bool ghost = plan->border == SM_GHOST;
 #define SM_GO(F, G) \
     hipLaunchKernelGGL((k_match_wta<MODE, F, G>), grid, block, g.lds_bytes, st, plan->d_ext, d_web, d_best, g)
