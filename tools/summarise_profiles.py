@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condense raw rocprofv3 output (tools/collect_profiles.sh) into the small
+files kept under profiles/<tag>/ and refresh profiles/hbm_traffic.json.
+
+    python tools/summarise_profiles.py gpurun_out/prof_r01 profiles/r01 [C3:1]
+"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+src, dst = Path(sys.argv[1]), Path(sys.argv[2])
+key = sys.argv[3] if len(sys.argv) > 3 else "C3:1"
+dst.mkdir(parents=True, exist_ok=True)
+
+for f in glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")):
+    shutil.copy(f, dst / "kernel_stats.csv")
+bench = [l for l in (src / "bench.json").read_text().splitlines() if l.startswith("{")]
+if bench:
+    (dst / "bench.json").write_text(bench[-1] + "\n")
+
+counters = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(str(src / "pmc_*" / "*" / "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        counters[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in counters.items()
+           if not k.startswith("__amd")}
+(dst / "pmc_summary.json").write_text(json.dumps(summary, indent=1, sort_keys=True) + "\n")
+
+# HBM traffic of the dominant kernel, per launch.  rocprofv3 reports FETCH_SIZE and
+# WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B, so the
+# read side is doubled (MI355X_MICROARCH.md, HBM section).  WRITE_SIZE is exact.
+traffic_file = dst.parent / "hbm_traffic.json"
+traffic = json.loads(traffic_file.read_text()) if traffic_file.exists() else {}
+for k, cs in summary.items():
+    if k.startswith("k_match_wta") and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        traffic[key] = {
+            "kernel": k,
+            "fetch_size_kib_raw": cs["FETCH_SIZE"],
+            "write_size_kib": cs["WRITE_SIZE"],
+            "bytes_per_launch": int((2.0 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
+            "note": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE half-count "
+                    "correction); L2->fabric requests, Infinity-Cache hits included",
+            "source": str(dst),
+        }
+traffic_file.write_text(json.dumps(traffic, indent=1, sort_keys=True) + "\n")
+print(json.dumps(summary, indent=1, sort_keys=True)[:3000])
