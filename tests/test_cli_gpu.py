@@ -1,0 +1,64 @@
+"""GPU test of the process boundary: the reference's own acceptance test
+(test/diff.sh) restated -- every PPM the GPU programs write in a debug build
+equals, byte for byte, what the serial programs write."""
+import os
+import subprocess
+from pathlib import Path
+
+import pytest
+
+from stereomatching_amd.synth import make_pair, write_pgm
+from tests.test_cli_cpu import STDOUT_RE, programs, run  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ser,par,sdir,pdir", [("stereomatch", "stereopar", "ser", "par"),
+                                               ("stereomatch-ghost", "stereopar-ghost", "sergh", "pargh")])
+@pytest.mark.parametrize("w,h,args,shifts", [
+    (120, 67, (0.15, 21, 32, 10), None),          # the reference's defaults, 96 files
+    (97, 64, (0.1, 8, 3, 4), "40"),               # STEREO_NUM_SHIFTS extension, 126 files
+])
+def test_diff_sh_equivalent(programs, tmp_path, ser, par, sdir, pdir, w, h, args, shifts):  # noqa: F811
+    left, right = make_pair(w, h, 30, seed=w)
+    write_pgm(tmp_path / "a.pgm", left)
+    write_pgm(tmp_path / "b.pgm", right)
+    os.mkdir(tmp_path / sdir)
+    os.mkdir(tmp_path / pdir)
+    env = dict(os.environ)
+    if shifts:
+        env["STEREO_NUM_SHIFTS"] = shifts
+    outs = []
+    for exe in (programs["debug"][ser], programs["debug"][par]):
+        p = subprocess.run([str(exe), "a.pgm", "b.pgm", *map(str, args)], cwd=tmp_path,
+                           capture_output=True, text=True, env=env)
+        assert p.returncode == 0, p.stderr
+        assert STDOUT_RE.match(p.stdout), p.stdout
+        outs.append(p.stdout)
+    names = sorted(f.name for f in (tmp_path / sdir).iterdir())
+    assert len(names) == 6 + 3 * int(shifts or 30)
+    assert names == sorted(f.name for f in (tmp_path / pdir).iterdir())
+    for name in names:
+        assert (tmp_path / sdir / name).read_bytes() == (tmp_path / pdir / name).read_bytes(), name
+
+
+def test_timing_build_runs_and_writes_nothing(programs, tmp_path):  # noqa: F811
+    left, right = make_pair(640, 360, 30, seed=3)
+    write_pgm(tmp_path / "a.pgm", left)
+    write_pgm(tmp_path / "b.pgm", right)
+    for prog in ("stereopar", "stereopar-ghost"):
+        p = run(programs["timing"][prog], "a.pgm", "b.pgm", cwd=tmp_path)
+        assert p.returncode == 0, p.stderr
+        m = STDOUT_RE.match(p.stdout)
+        assert m and (m.group(1), m.group(2)) == ("640", "360")
+        assert p.stdout.split()[14] == m.group(3)          # awk '{print $15}' of test/time.sh
+    assert not list(tmp_path.glob("*.ppm"))
+
+
+def test_zero_contour_interval_is_reported(programs, tmp_path):  # noqa: F811
+    # a constant pair gives a constant web: the reference divides by a zero interval
+    left, right = make_pair(64, 48, 30, kind="constant")
+    write_pgm(tmp_path / "a.pgm", left)
+    write_pgm(tmp_path / "b.pgm", right)
+    p = run(programs["timing"]["stereopar"], "a.pgm", "b.pgm", 0.15, 5, cwd=tmp_path)
+    assert p.returncode == 1 and "contour interval is zero" in p.stderr
