@@ -123,6 +123,14 @@ int sm_debug_planes(sm_plan *plan, int pair, int shift, uint8_t *d_match,
  * test prove the device arithmetic equals the host's for a threshold.       */
 int sm_debug_edge_table(int device, double threshold, uint8_t *d_table, void *stream);
 
+/* debug tap: the same table, but decided the way sm_find_edges decides it --
+ * through the per-threshold integer lo/hi tables.
+ * *not_threshold_form is set to 1 if the exact test was found not to be of
+ * "true prefix / false middle / true suffix" form for some left sum, in which
+ * case sm_find_edges falls back to the double arithmetic.  Synchronises.     */
+int sm_debug_edge_table_fast(sm_plan *plan, double threshold, uint8_t *d_table,
+                             int *not_threshold_form, void *stream);
+
 /* ---- step 3 -------------------------------------------------------------- *
  * fill_web_holes (src/stereo.cu:235-256): `times` Jacobi sweeps over pixels
  * that are 0, ping-ponging d_web and d_tmp exactly as the reference swaps

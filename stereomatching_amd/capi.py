@@ -53,6 +53,7 @@ _SIGNATURES = {
     "sm_run": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp]),
     "sm_debug_planes": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp]),
     "sm_debug_edge_table": (_int, [_int, _dbl, _vp, _vp]),
+    "sm_debug_edge_table_fast": (_int, [_vp, _dbl, _vp, _intp, _vp]),
     "sm_fill_web_holes": (_int, [_vp, _vp, _vp, _int, _int, _intp, _vp]),
     "sm_min_max": (_int, [_vp, _vp, _int, _vp, _vp]),
     "sm_draw_contour_map": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),

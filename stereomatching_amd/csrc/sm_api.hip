@@ -95,6 +95,138 @@ __global__ void k_edge_table(double threshold, u8 *__restrict__ table)
     if (sb < 766) table[sa * 766 + sb] = contrast_test(sa, sb, threshold);
 }
 
+// Per-threshold decision tables.  For a fixed left sum sa the exact test is
+// true for right sums sb <= lo(sa) and sb >= hi(sa) and false in between: with
+// sb moving away from sa, |ma - mb| grows by 1/768 per unit and the limit
+// threshold*(ma+mb)/2 by at most 1/1536, so the difference is monotone by a
+// margin of ~1e-3, far above the rounding of the double operations.  The
+// tables are BUILT with the exact double test (one workgroup per sa evaluates
+// all 766 sb) and the threshold form is VERIFIED while building: if any row is
+// not "true prefix, false middle, true suffix", bad_flag is raised and the
+// edge kernel keeps using the double arithmetic.  The edge kernel then needs
+// two integer compares per orientation instead of two double divisions.
+__global__ __launch_bounds__(256) void k_edge_thresholds(double threshold, u32 *__restrict__ tab,
+                                                         i32 *__restrict__ bad_flag)
+{
+    __shared__ int lo, hi, n_lo, n_hi;
+    const int sa = blockIdx.x;
+    if (threadIdx.x == 0) { lo = -1; hi = 766; n_lo = 0; n_hi = 0; }
+    __syncthreads();
+    for (int sb = threadIdx.x; sb < 766; sb += blockDim.x) {
+        if (contrast_test(sa, sb, threshold)) {
+            if (sb <= sa) { atomicMax(&lo, sb); atomicAdd(&n_lo, 1); }
+            if (sb >= sa) { atomicMin(&hi, sb); atomicAdd(&n_hi, 1); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tab[sa] = (u32)(lo & 0xffff) | ((u32)hi << 16);   // lo = -1 -> 0xffff (never <=)
+        if (n_lo != lo + 1 || n_hi != 766 - hi) atomicOr(bad_flag, 1);
+    }
+}
+
+__global__ void k_edge_table_fast(const u32 *__restrict__ tab, u8 *__restrict__ table)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x, sa = blockIdx.y;
+    if (sb >= 766) return;
+    const u32 lh = tab[sa];
+    table[sa * 766 + sb] = sb <= (int)(short)(lh & 0xffff) || sb >= (int)(lh >> 16);
+}
+
+#define SM_EDGE_ROWS 4   // ext rows per workgroup of the edge kernel
+#define SM_EDGE_TW 256   // ext pixels per workgroup row
+
+// Edge detection straight into the packed ext image.  A workgroup owns
+// 256 x 4 ext pixels: it stages the 6 gray rows it needs once in LDS (u16, so
+// that the ghost halo 128.0 = 32768/256 fits), then every lane tests one
+// pixel per row and the wave's 64 decisions become two ext words via ballot.
+template <bool GHOST>
+__global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
+                                                   const u8 *__restrict__ src_r,
+                                                   u8 *__restrict__ edges_l,
+                                                   u8 *__restrict__ edges_r,
+                                                   u32 *__restrict__ ext,
+                                                   const u32 *__restrict__ tab_g,
+                                                   const i32 *__restrict__ tab_bad,
+                                                   const MatchGeom g, double threshold)
+{
+    __shared__ unsigned short gray[SM_EDGE_ROWS + 2][SM_EDGE_TW + 4];
+    __shared__ u32 tab[768];
+    const int tid = threadIdx.x;
+    const int xe0 = blockIdx.x * SM_EDGE_TW, ye0 = blockIdx.y * SM_EDGE_ROWS;
+    const int pair = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const size_t img = (size_t)pair * g.w * g.h;
+    const u8 *src = (side ? src_r : src_l) + img;
+    u8 *edges = side ? edges_r : edges_l;
+    const bool use_tab = *tab_bad == 0;
+
+    for (int i = tid; i < 766; i += 256) tab[i] = tab_g[i];
+    // staged position (r, c) is image coordinate (xe0 - pad_l - 1 + c, ye0 - half - 1 + r)
+    for (int i = tid; i < (SM_EDGE_ROWS + 2) * (SM_EDGE_TW + 2); i += 256) {
+        const int r = i / (SM_EDGE_TW + 2), c = i - r * (SM_EDGE_TW + 2);
+        int x = xe0 - g.pad_l - 1 + c, y = ye0 - g.half - 1 + r;
+        unsigned short v;
+        if (GHOST) {
+            const bool in = x >= 0 && x < g.w && y >= 0 && y < g.h;
+            v = in ? src[(size_t)y * g.w + x] : (unsigned short)32768;
+        } else {
+            x = pos_mod(x, g.w);
+            y = pos_mod(y, g.h);
+            v = src[(size_t)y * g.w + x];
+        }
+        gray[r][c] = v;
+    }
+    __syncthreads();
+
+    const int xe = xe0 + tid;
+    const int x = xe - g.pad_l;
+#pragma unroll
+    for (int rr = 0; rr < SM_EDGE_ROWS; rr++) {
+        const int ye = ye0 + rr;
+        if (ye >= g.ext_rows) break;                 // uniform
+        const int y = ye - g.half;
+        const bool inside = x >= 0 && x < g.w && y >= 0 && y < g.h;
+        u32 val = 0;
+        if (xe < g.ext_words * 32 && (inside || !GHOST)) {
+            // v[row][col]: row 0 = y-1, col 0 = x-1
+            int v[3][3];
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) v[dy][dx] = gray[rr + dy][tid + dx];
+            const int sa[4] = {v[0][0] + v[1][0] + v[2][0],      // left      src/stereo.c:16-28
+                               v[0][0] + v[0][1] + v[0][2],      // top       src/stereo.c:30-42
+                               v[0][0] + v[0][1] + v[1][0],      // up-left   src/stereo.c:44-56
+                               v[2][0] + v[2][1] + v[1][0]};     // down-left src/stereo.c:58-70
+            const int sb[4] = {v[0][2] + v[1][2] + v[2][2],      // right
+                               v[2][0] + v[2][1] + v[2][2],      // bottom
+                               v[1][2] + v[2][1] + v[2][2],      // down-right
+                               v[0][1] + v[0][2] + v[1][2]};     // up-right
+            bool e = false;
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                bool t;
+                if (use_tab && (!GHOST || (sa[o] < 766 && sb[o] < 766))) {
+                    const u32 lh = tab[sa[o]];
+                    t = sb[o] <= (int)(short)(lh & 0xffff) || sb[o] >= (int)(lh >> 16);
+                } else {
+                    t = contrast_test(sa[o], sb[o], threshold);
+                }
+                e |= t;
+            }
+            val = e;
+            if (inside && edges) edges[img + (size_t)y * g.w + x] = (u8)val;
+        }
+        const unsigned long long bal = __ballot(val != 0);
+        if ((tid & 63) == 0) {
+            u32 *row = ext + ((size_t)blockIdx.z * g.ext_rows + ye) * g.ext_words;
+            const int wd = xe >> 5;
+            if (wd < g.ext_words) row[wd] = (u32)bal;
+            if (wd + 1 < g.ext_words) row[wd + 1] = (u32)(bal >> 32);
+        }
+    }
+}
+
 // One lane per ext pixel; a wave's 64 decisions become two ext words via
 // ballot.  FROM_GRAY: run the edge test; otherwise read a u8 {0,1} edge image.
 template <bool FROM_GRAY>
@@ -339,11 +471,13 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
     p->ext_bytes = (size_t)max_pairs * 2 * (size_t)p->g.ext_image_words * sizeof(u32);
     hipError_t e = hipMalloc((void **)&p->d_ext, p->ext_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flags, 4 * sizeof(i32));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_edge_tab, 768 * sizeof(u32));
     if (e == hipSuccess) e = hipMemset(p->d_ext, 0, p->ext_bytes);
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(i32));
     if (e != hipSuccess) {
         if (p->d_ext) (void)hipFree(p->d_ext);
         if (p->d_flags) (void)hipFree(p->d_flags);
+        if (p->d_edge_tab) (void)hipFree(p->d_edge_tab);
         free(p);
         return sm_fail(e == hipErrorOutOfMemory ? SM_ERR_NOMEM : SM_ERR_HIP,
                        "sm_plan_create: workspace allocation failed: %s", hipGetErrorString(e));
@@ -358,6 +492,7 @@ extern "C" void sm_plan_destroy(sm_plan *plan)
     (void)hipSetDevice(plan->device);
     (void)hipFree(plan->d_ext);
     (void)hipFree(plan->d_flags);
+    (void)hipFree(plan->d_edge_tab);
     free(plan);
 }
 
@@ -390,6 +525,37 @@ static int fill_ext(sm_plan *plan, const u8 *l, const u8 *r, double threshold, i
     return SM_OK;
 }
 
+// decision tables depend on the threshold only: rebuilt when it changes
+static int ensure_edge_tables(sm_plan *plan, double threshold, hipStream_t st)
+{
+    if (plan->tab_valid && memcmp(&plan->tab_threshold, &threshold, sizeof threshold) == 0)
+        return SM_OK;
+    SM_HIP(hipMemsetAsync(&plan->d_flags[2], 0, sizeof(i32), st));
+    hipLaunchKernelGGL(k_edge_thresholds, dim3(766), dim3(256), 0, st, threshold,
+                       plan->d_edge_tab, &plan->d_flags[2]);
+    SM_LAUNCH_CHECK("k_edge_thresholds");
+    plan->tab_threshold = threshold;
+    plan->tab_valid = 1;
+    return SM_OK;
+}
+
+extern "C" int sm_debug_edge_table_fast(sm_plan *plan, double threshold, uint8_t *d_table,
+                                        int *not_threshold_form, void *stream)
+{
+    if (!plan || !d_table || !not_threshold_form)
+        return sm_fail(SM_ERR_ARG, "sm_debug_edge_table_fast: NULL argument");
+    SM_TRY(use_device(plan->device));
+    hipStream_t st = (hipStream_t)stream;
+    SM_TRY(ensure_edge_tables(plan, threshold, st));
+    hipLaunchKernelGGL(k_edge_table_fast, dim3(3, 766), dim3(256), 0, st, plan->d_edge_tab, d_table);
+    SM_LAUNCH_CHECK("k_edge_table_fast");
+    i32 bad = 0;
+    SM_HIP(hipMemcpyAsync(&bad, &plan->d_flags[2], sizeof(i32), hipMemcpyDeviceToHost, st));
+    SM_HIP(hipStreamSynchronize(st));
+    *not_threshold_form = bad;
+    return SM_OK;
+}
+
 extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
                              const uint8_t *d_gray_right, double threshold, int pairs,
                              uint8_t *d_edges_left, uint8_t *d_edges_right, void *stream)
@@ -400,8 +566,22 @@ extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
     if (!(threshold >= 0.0 && threshold <= 1.0))
         return sm_fail(SM_ERR_ARG, "error: threshold must be between 0 and 1");
     SM_TRY(use_device(plan->device));
-    return fill_ext<true>(plan, d_gray_left, d_gray_right, threshold, pairs, d_edges_left,
-                          d_edges_right, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    SM_TRY(ensure_edge_tables(plan, threshold, st));
+    const MatchGeom &g = plan->g;
+    const dim3 grid((g.ext_words * 32 + SM_EDGE_TW - 1) / SM_EDGE_TW,
+                    (g.ext_rows + SM_EDGE_ROWS - 1) / SM_EDGE_ROWS, pairs * 2), block(256);
+    if (plan->border == SM_GHOST)
+        hipLaunchKernelGGL((k_edges_ext<true>), grid, block, 0, st, d_gray_left, d_gray_right,
+                           d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab,
+                           &plan->d_flags[2], g, threshold);
+    else
+        hipLaunchKernelGGL((k_edges_ext<false>), grid, block, 0, st, d_gray_left, d_gray_right,
+                           d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab,
+                           &plan->d_flags[2], g, threshold);
+    SM_LAUNCH_CHECK("k_edges_ext");
+    plan->pairs_loaded = pairs;
+    return SM_OK;
 }
 
 extern "C" int sm_load_edges(sm_plan *plan, const uint8_t *d_edges_left,

@@ -63,7 +63,11 @@ struct sm_plan {
     MatchGeom g;
     u32 *d_ext;          // packed edge images
     size_t ext_bytes;
-    i32 *d_flags;        // [0] = zero-interval flag
+    i32 *d_flags;        // [0] = zero-interval flag, [1] = has-zero scratch,
+                         // [2] = edge table is not of threshold form
+    u32 *d_edge_tab;     // 766 x {lo | hi << 16}: edge iff sb <= lo || sb >= hi
+    double tab_threshold;  // threshold d_edge_tab was built for
+    int tab_valid;
     int pairs_loaded;    // batch size of the edges currently in d_ext
     char describe[512];
 };

@@ -160,6 +160,24 @@ def test_edge_decision_exhaustive(hip, thr):
     assert np.array_equal(host(tab), oracle.edge_table(thr))
 
 
+def test_edge_threshold_tables_exhaustive(hip):
+    """the integer lo/hi tables sm_find_edges decides with reproduce the exact double
+    test for every pair of in-image sums, for round and for random thresholds"""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    thresholds = [0.0, 1.0, 0.15, 0.5, 0.25, 0.75, 1.0 / 3.0, 2.0 / 3.0, 1e-9, 0.999999,
+                  *rng.random(20).tolist()]
+    plan = hip.StereoPlan(32, 32, 16, 5)
+    tab = torch.empty((766, 766), dtype=torch.uint8, device="cuda")
+    for thr in thresholds:
+        bad = C.c_int(-1)
+        hip.capi.check(hip.capi.lib.sm_debug_edge_table_fast(plan._h, thr, C.c_void_p(tab.data_ptr()),
+                                                             C.byref(bad), None))
+        assert bad.value == 0, thr
+        assert np.array_equal(host(tab), oracle.edge_table(thr)), thr
+    plan.close()
+
+
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 @pytest.mark.parametrize("w,h,kind,thr", [
     (64, 48, "scene", 0.15), (301, 97, "scene", 0.15), (130, 77, "noise", 0.5),
