@@ -125,138 +125,183 @@ __global__ __launch_bounds__(256) void k_edge_thresholds(double threshold, u32 *
     }
 }
 
-__global__ void k_edge_table_fast(const u32 *__restrict__ tab, u8 *__restrict__ table)
+// Integer prefilter in front of the tables.  In exact arithmetic the test is
+// |sa - sb| > threshold * (sa + sb) / 2 (the clamp to [0,1] never binds for
+// in-image sums).  With T = round(threshold/2 * 2^20),
+//     delta = |sa - sb| * 2^20 - (sa + sb) * T
+// differs from 2^20 * (|sa-sb| - threshold*(sa+sb)/2) by at most 0.5 * 1530 = 765,
+// so |delta| > 1024 leaves a real margin of > 2.4e-4 sum units, i.e. a relative
+// margin > 1e-7 on quantities the double evaluation gets right to ~1e-15: the
+// sign of delta IS the double decision.  Only |delta| <= 1024 (the few sum pairs
+// next to the boundary) consults the table.  Same function in the edge kernel
+// and in the exhaustive debug table, so the test covers what runs.
+#define SM_EDGE_FIX 20
+#define SM_EDGE_MARGIN 1024
+__device__ __forceinline__ int edge_delta(int sa, int sb, int t_fix)
+{
+    const int d = sa - sb;
+    // sums < 2^11 and t_fix <= 2^19: the 24-bit multiply is exact
+    return ((d < 0 ? -d : d) << SM_EDGE_FIX) - (int)__umul24((u32)(sa + sb), (u32)t_fix);
+}
+__device__ __forceinline__ bool edge_from_table(const u32 *tab, int sa, int sb)
+{
+    const u32 lh = tab[sa];
+    return sb <= (int)(short)(lh & 0xffff) || sb >= (int)(lh >> 16);
+}
+
+__global__ void k_edge_table_fast(const u32 *__restrict__ tab, int t_fix, u8 *__restrict__ table)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x, sa = blockIdx.y;
     if (sb >= 766) return;
-    const u32 lh = tab[sa];
-    table[sa * 766 + sb] = sb <= (int)(short)(lh & 0xffff) || sb >= (int)(lh >> 16);
+    const int delta = edge_delta(sa, sb, t_fix);
+    table[sa * 766 + sb] = delta > SM_EDGE_MARGIN ? 1 : delta < -SM_EDGE_MARGIN ? 0
+                                                      : edge_from_table(tab, sa, sb);
 }
 
-#define SM_EDGE_ROWS 4   // ext rows per workgroup of the edge kernel
-#define SM_EDGE_TW 256   // ext pixels per workgroup row
+#define SM_EDGE_ROWS 32   // ext rows one wave walks down
 
-// Edge detection straight into the packed ext image.  A workgroup owns
-// 256 x 4 ext pixels: it stages the 6 gray rows it needs once in LDS (u16, so
-// that the ghost halo 128.0 = 32768/256 fits), then every lane tests one
-// pixel per row and the wave's 64 decisions become two ext words via ballot.
-template <bool GHOST>
+// Edge detection straight into the packed ext image.  No LDS, no barrier: a
+// wave owns a strip of 64 ext pixels x SM_EDGE_ROWS ext rows and walks down it;
+// each lane keeps the 3 x 3 gray neighbourhood of its pixel in registers and
+// loads three bytes (x-1, x, x+1) of the next row per step, so the loads of
+// row y+2 are in flight while row y is decided.  The wave's 64 decisions become
+// two ext words via ballot.  Border rule at load time: wrapped coordinates
+// (toroidal) or the 128.0 halo, 32768 in units of 1/256 (ghost).
+//
+// The per-pixel decision is integer arithmetic on purpose (sign bits, no bool
+// short-circuits): compares feeding && / || turn into SGPR-mask traffic, and an
+// earlier version of this kernel was bound by the CU's scalar issue port.
+template <bool GHOST, bool TABLES>
 __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
                                                    const u8 *__restrict__ src_r,
                                                    u8 *__restrict__ edges_l,
                                                    u8 *__restrict__ edges_r,
                                                    u32 *__restrict__ ext,
-                                                   const u32 *__restrict__ tab_g,
-                                                   const i32 *__restrict__ tab_bad,
-                                                   const MatchGeom g, double threshold)
+                                                   const u32 *__restrict__ tab,
+                                                   const MatchGeom g, double threshold, int t_fix)
 {
-    __shared__ unsigned short gray[SM_EDGE_ROWS + 2][SM_EDGE_TW + 4];
-    __shared__ u32 tab[768];
     const int tid = threadIdx.x;
-    const int xe0 = blockIdx.x * SM_EDGE_TW, ye0 = blockIdx.y * SM_EDGE_ROWS;
+    const int xe = blockIdx.x * 256 + tid;
+    const int ye0 = blockIdx.y * SM_EDGE_ROWS;
     const int pair = blockIdx.z >> 1, side = blockIdx.z & 1;
     const size_t img = (size_t)pair * g.w * g.h;
     const u8 *src = (side ? src_r : src_l) + img;
     u8 *edges = side ? edges_r : edges_l;
-    const bool use_tab = *tab_bad == 0;
 
-    for (int i = tid; i < 766; i += 256) tab[i] = tab_g[i];
-    // staged position (r, c) is image coordinate (xe0 - pad_l - 1 + c, ye0 - half - 1 + r)
-    for (int i = tid; i < (SM_EDGE_ROWS + 2) * (SM_EDGE_TW + 2); i += 256) {
-        const int r = i / (SM_EDGE_TW + 2), c = i - r * (SM_EDGE_TW + 2);
-        int x = xe0 - g.pad_l - 1 + c, y = ye0 - g.half - 1 + r;
-        unsigned short v;
-        if (GHOST) {
-            const bool in = x >= 0 && x < g.w && y >= 0 && y < g.h;
-            v = in ? src[(size_t)y * g.w + x] : (unsigned short)32768;
-        } else {
-            x = pos_mod(x, g.w);
-            y = pos_mod(y, g.h);
-            v = src[(size_t)y * g.w + x];
-        }
-        gray[r][c] = v;
-    }
-    __syncthreads();
-
-    const int xe = xe0 + tid;
     const int x = xe - g.pad_l;
+    const u32 in_x = (xe < g.ext_words * 32 && (!GHOST || (x >= 0 && x < g.w))) ? 1u : 0u;
+    const bool store_x = x >= 0 && x < g.w && edges != nullptr;
+    u32 *ext_img = ext + (size_t)blockIdx.z * g.ext_rows * g.ext_words;
+    const int wd = xe >> 5;
+
+    // source columns of x-1, x, x+1
+    int xc[3];
+    bool vx[3];
+    if (GHOST) {
 #pragma unroll
-    for (int rr = 0; rr < SM_EDGE_ROWS; rr++) {
-        const int ye = ye0 + rr;
-        if (ye >= g.ext_rows) break;                 // uniform
-        const int y = ye - g.half;
-        const bool inside = x >= 0 && x < g.w && y >= 0 && y < g.h;
-        u32 val = 0;
-        if (xe < g.ext_words * 32 && (inside || !GHOST)) {
-            // v[row][col]: row 0 = y-1, col 0 = x-1
-            int v[3][3];
-#pragma unroll
-            for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-                for (int dx = 0; dx < 3; dx++) v[dy][dx] = gray[rr + dy][tid + dx];
-            const int sa[4] = {v[0][0] + v[1][0] + v[2][0],      // left      src/stereo.c:16-28
-                               v[0][0] + v[0][1] + v[0][2],      // top       src/stereo.c:30-42
-                               v[0][0] + v[0][1] + v[1][0],      // up-left   src/stereo.c:44-56
-                               v[2][0] + v[2][1] + v[1][0]};     // down-left src/stereo.c:58-70
-            const int sb[4] = {v[0][2] + v[1][2] + v[2][2],      // right
-                               v[2][0] + v[2][1] + v[2][2],      // bottom
-                               v[1][2] + v[2][1] + v[2][2],      // down-right
-                               v[0][1] + v[0][2] + v[1][2]};     // up-right
-            bool e = false;
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                bool t;
-                if (use_tab && (!GHOST || (sa[o] < 766 && sb[o] < 766))) {
-                    const u32 lh = tab[sa[o]];
-                    t = sb[o] <= (int)(short)(lh & 0xffff) || sb[o] >= (int)(lh >> 16);
-                } else {
-                    t = contrast_test(sa[o], sb[o], threshold);
-                }
-                e |= t;
-            }
-            val = e;
-            if (inside && edges) edges[img + (size_t)y * g.w + x] = (u8)val;
+        for (int k = 0; k < 3; k++) {
+            const int xx = x - 1 + k;
+            vx[k] = xx >= 0 && xx < g.w;
+            xc[k] = vx[k] ? xx : 0;
         }
+    } else {
+        xc[1] = pos_mod(x, g.w);
+        xc[0] = xc[1] == 0 ? g.w - 1 : xc[1] - 1;
+        xc[2] = xc[1] + 1 == g.w ? 0 : xc[1] + 1;
+        vx[0] = vx[1] = vx[2] = true;
+    }
+
+    // rows: image row of ext row ye is ye - half; the walk starts one above
+    int y_img = ye0 - g.half - 1;
+    int ys = GHOST ? y_img : pos_mod(y_img, g.h);       // source row (toroidal: wrapped)
+    auto load_row = [&](int (&o)[3]) {
+        const bool vy = !GHOST || (y_img >= 0 && y_img < g.h);
+        const u8 *row = src + (size_t)(vy ? ys : 0) * g.w;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int v = row[xc[k]];
+            o[k] = (vy && vx[k]) ? v : 32768;
+        }
+        y_img++;
+        ys = GHOST ? y_img : (ys + 1 == g.h ? 0 : ys + 1);
+    };
+
+    int v[3][3];          // v[row][col]: row 0 = y-1, col 0 = x-1
+    load_row(v[0]);
+    load_row(v[1]);
+    const int rows = min(SM_EDGE_ROWS, g.ext_rows - ye0);
+    for (int rr = 0; rr < rows; rr++) {
+        load_row(v[2]);
+        const int ye = ye0 + rr;
+        const int y = ye - g.half;
+        const bool in_y = y >= 0 && y < g.h;         // uniform
+        const int sa[4] = {v[0][0] + v[1][0] + v[2][0],      // left      src/stereo.c:16-28
+                           v[0][0] + v[0][1] + v[0][2],      // top       src/stereo.c:30-42
+                           v[0][0] + v[0][1] + v[1][0],      // up-left   src/stereo.c:44-56
+                           v[2][0] + v[2][1] + v[1][0]};     // down-left src/stereo.c:58-70
+        const int sb[4] = {v[0][2] + v[1][2] + v[2][2],      // right
+                           v[2][0] + v[2][1] + v[2][2],      // bottom
+                           v[1][2] + v[2][1] + v[2][2],      // down-right
+                           v[0][1] + v[0][2] + v[1][2]};     // up-right
+        u32 e;
+        if (!TABLES) {
+            e = 0;
+#pragma unroll
+            for (int o = 0; o < 4; o++) e |= contrast_test(sa[o], sb[o], threshold) ? 1u : 0u;
+        } else {
+            int dl[4];
+#pragma unroll
+            for (int o = 0; o < 4; o++) dl[o] = edge_delta(sa[o], sb[o], t_fix);
+            const int dmax = max(max(dl[0], dl[1]), max(dl[2], dl[3]));
+            e = (u32)(SM_EDGE_MARGIN - dmax) >> 31;                  // dmax > margin
+            // rare: the deciding sum pair is next to the boundary -> ask the table
+            if ((u32)(dmax + SM_EDGE_MARGIN) <= 2u * SM_EDGE_MARGIN) {
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                    if (dl[o] >= -SM_EDGE_MARGIN) e |= edge_from_table(tab, sa[o], sb[o]) ? 1u : 0u;
+            }
+            if (GHOST) {
+                // sums that contain the halo (image-border pixels only) are outside
+                // the tables: exact double arithmetic
+                const int smax = max(max(max(sa[0], sb[0]), max(sa[1], sb[1])),
+                                     max(max(sa[2], sb[2]), max(sa[3], sb[3])));
+                if (smax >= 766) {
+                    e = 0;
+#pragma unroll
+                    for (int o = 0; o < 4; o++) e |= contrast_test(sa[o], sb[o], threshold) ? 1u : 0u;
+                }
+            }
+        }
+        const u32 val = e & in_x & ((!GHOST || in_y) ? 1u : 0u);
+        if (store_x && in_y) edges[img + (size_t)y * g.w + x] = (u8)val;
         const unsigned long long bal = __ballot(val != 0);
         if ((tid & 63) == 0) {
-            u32 *row = ext + ((size_t)blockIdx.z * g.ext_rows + ye) * g.ext_words;
-            const int wd = xe >> 5;
+            u32 *row = ext_img + (size_t)ye * g.ext_words;
             if (wd < g.ext_words) row[wd] = (u32)bal;
             if (wd + 1 < g.ext_words) row[wd + 1] = (u32)(bal >> 32);
         }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v[0][k] = v[1][k]; v[1][k] = v[2][k]; }
     }
 }
 
-// One lane per ext pixel; a wave's 64 decisions become two ext words via
-// ballot.  FROM_GRAY: run the edge test; otherwise read a u8 {0,1} edge image.
-template <bool FROM_GRAY>
-__global__ __launch_bounds__(256) void k_fill_ext(const u8 *__restrict__ src_l,
+// u8 {0,1} edge image -> packed ext image (the sm_load_edges entry).  One lane
+// per ext pixel; a wave's 64 values become two ext words via ballot.
+__global__ __launch_bounds__(256) void k_pack_ext(const u8 *__restrict__ src_l,
                                                   const u8 *__restrict__ src_r,
-                                                  u8 *__restrict__ edges_l,
-                                                  u8 *__restrict__ edges_r,
-                                                  u32 *__restrict__ ext, const MatchGeom g,
-                                                  double threshold, int ghost)
+                                                  u32 *__restrict__ ext, const MatchGeom g, int ghost)
 {
     const int xe = blockIdx.x * blockDim.x + threadIdx.x;
     const int ye = blockIdx.y;
     const int pair = blockIdx.z >> 1, side = blockIdx.z & 1;
-    const size_t img = (size_t)pair * g.w * g.h;
-    const u8 *src = (side ? src_r : src_l) + img;
-    u8 *edges = side ? edges_r : edges_l;
-
+    const u8 *src = (side ? src_r : src_l) + (size_t)pair * g.w * g.h;
     const int x = xe - g.pad_l, y = ye - g.half;
     const bool inside = x >= 0 && x < g.w && y >= 0 && y < g.h;
     u32 val = 0;
-    if (xe < g.ext_words * 32) {
-        if (inside || !ghost) {
-            const int xs = inside ? x : pos_mod(x, g.w);
-            const int ys = inside ? y : pos_mod(y, g.h);
-            if (FROM_GRAY)
-                val = edge_at(src, g.w, g.h, xs, ys, threshold, ghost != 0);
-            else
-                val = src[(size_t)ys * g.w + xs] != 0;
-        }
-        if (FROM_GRAY && inside && edges) edges[img + (size_t)y * g.w + x] = (u8)val;
+    if (xe < g.ext_words * 32 && (inside || !ghost)) {
+        const int xs = inside ? x : pos_mod(x, g.w);
+        const int ys = inside ? y : pos_mod(y, g.h);
+        val = src[(size_t)ys * g.w + xs] != 0;
     }
     const unsigned long long bal = __ballot(val != 0);
     if ((threadIdx.x & 63) == 0) {
@@ -512,17 +557,20 @@ static int check_plan_pairs(const sm_plan *plan, int pairs, const char *who)
     return SM_OK;
 }
 
-template <bool FROM_GRAY>
-static int fill_ext(sm_plan *plan, const u8 *l, const u8 *r, double threshold, int pairs,
-                    u8 *el, u8 *er, hipStream_t st)
+static int pack_ext(sm_plan *plan, const u8 *l, const u8 *r, int pairs, hipStream_t st)
 {
     const MatchGeom &g = plan->g;
     const dim3 grid((g.ext_words * 32 + 255) / 256, g.ext_rows, pairs * 2), block(256);
-    hipLaunchKernelGGL((k_fill_ext<FROM_GRAY>), grid, block, 0, st, l, r, el, er, plan->d_ext, g,
-                       threshold, plan->border == SM_GHOST ? 1 : 0);
-    SM_LAUNCH_CHECK("k_fill_ext");
+    hipLaunchKernelGGL(k_pack_ext, grid, block, 0, st, l, r, plan->d_ext, g,
+                       plan->border == SM_GHOST ? 1 : 0);
+    SM_LAUNCH_CHECK("k_pack_ext");
     plan->pairs_loaded = pairs;
     return SM_OK;
+}
+
+static int edge_t_fix(double threshold)
+{
+    return (int)(threshold * 0.5 * (double)(1 << SM_EDGE_FIX) + 0.5);
 }
 
 // decision tables depend on the threshold only: rebuilt when it changes
@@ -534,6 +582,12 @@ static int ensure_edge_tables(sm_plan *plan, double threshold, hipStream_t st)
     hipLaunchKernelGGL(k_edge_thresholds, dim3(766), dim3(256), 0, st, threshold,
                        plan->d_edge_tab, &plan->d_flags[2]);
     SM_LAUNCH_CHECK("k_edge_thresholds");
+    // read the verdict back once per new threshold (not in the steady state): it
+    // selects the kernel instantiation
+    i32 bad = 0;
+    SM_HIP(hipMemcpyAsync(&bad, &plan->d_flags[2], sizeof(i32), hipMemcpyDeviceToHost, st));
+    SM_HIP(hipStreamSynchronize(st));
+    plan->tab_ok = bad == 0;
     plan->tab_threshold = threshold;
     plan->tab_valid = 1;
     return SM_OK;
@@ -547,7 +601,8 @@ extern "C" int sm_debug_edge_table_fast(sm_plan *plan, double threshold, uint8_t
     SM_TRY(use_device(plan->device));
     hipStream_t st = (hipStream_t)stream;
     SM_TRY(ensure_edge_tables(plan, threshold, st));
-    hipLaunchKernelGGL(k_edge_table_fast, dim3(3, 766), dim3(256), 0, st, plan->d_edge_tab, d_table);
+    hipLaunchKernelGGL(k_edge_table_fast, dim3(3, 766), dim3(256), 0, st, plan->d_edge_tab,
+                       edge_t_fix(threshold), d_table);
     SM_LAUNCH_CHECK("k_edge_table_fast");
     i32 bad = 0;
     SM_HIP(hipMemcpyAsync(&bad, &plan->d_flags[2], sizeof(i32), hipMemcpyDeviceToHost, st));
@@ -569,16 +624,16 @@ extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
     hipStream_t st = (hipStream_t)stream;
     SM_TRY(ensure_edge_tables(plan, threshold, st));
     const MatchGeom &g = plan->g;
-    const dim3 grid((g.ext_words * 32 + SM_EDGE_TW - 1) / SM_EDGE_TW,
-                    (g.ext_rows + SM_EDGE_ROWS - 1) / SM_EDGE_ROWS, pairs * 2), block(256);
-    if (plan->border == SM_GHOST)
-        hipLaunchKernelGGL((k_edges_ext<true>), grid, block, 0, st, d_gray_left, d_gray_right,
-                           d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab,
-                           &plan->d_flags[2], g, threshold);
-    else
-        hipLaunchKernelGGL((k_edges_ext<false>), grid, block, 0, st, d_gray_left, d_gray_right,
-                           d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab,
-                           &plan->d_flags[2], g, threshold);
+    const dim3 grid((g.ext_words * 32 + 255) / 256, (g.ext_rows + SM_EDGE_ROWS - 1) / SM_EDGE_ROWS,
+                    pairs * 2), block(256);
+#define SM_EDGES_GO(G, T)                                                                    \
+    hipLaunchKernelGGL((k_edges_ext<G, T>), grid, block, 0, st, d_gray_left, d_gray_right,      \
+                       d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab, g, threshold, \
+                       edge_t_fix(threshold))
+    const bool ghost = plan->border == SM_GHOST;
+    if (plan->tab_ok) { if (ghost) SM_EDGES_GO(true, true); else SM_EDGES_GO(false, true); }
+    else              { if (ghost) SM_EDGES_GO(true, false); else SM_EDGES_GO(false, false); }
+#undef SM_EDGES_GO
     SM_LAUNCH_CHECK("k_edges_ext");
     plan->pairs_loaded = pairs;
     return SM_OK;
@@ -591,8 +646,7 @@ extern "C" int sm_load_edges(sm_plan *plan, const uint8_t *d_edges_left,
     if (!d_edges_left || !d_edges_right)
         return sm_fail(SM_ERR_ARG, "sm_load_edges: edge image pointer is NULL");
     SM_TRY(use_device(plan->device));
-    return fill_ext<false>(plan, d_edges_left, d_edges_right, 0.0, pairs, nullptr, nullptr,
-                           (hipStream_t)stream);
+    return pack_ext(plan, d_edges_left, d_edges_right, pairs, (hipStream_t)stream);
 }
 
 extern "C" int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d_best,

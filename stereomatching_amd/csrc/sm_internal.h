@@ -68,6 +68,7 @@ struct sm_plan {
     u32 *d_edge_tab;     // 766 x {lo | hi << 16}: edge iff sb <= lo || sb >= hi
     double tab_threshold;  // threshold d_edge_tab was built for
     int tab_valid;
+    int tab_ok;          // tables verified to be of threshold form
     int pairs_loaded;    // batch size of the edges currently in d_ext
     char describe[512];
 };
