@@ -28,7 +28,7 @@ typedef int32_t i32;
 // Workspace layout: [pair][side: 0 = left, 1 = right][ext_rows][ext_words].
 // ---------------------------------------------------------------------------
 
-enum { SM_KERNEL_A = 0, SM_KERNEL_B = 1, SM_KERNEL_C = 2, SM_KERNEL_GENERIC = 3 };
+enum { SM_KERNEL_A = 0, SM_KERNEL_B = 1, SM_KERNEL_C = 2, SM_KERNEL_GENERIC = 3, SM_KERNEL_BS = 4 };
 
 #define SM_DSET 16   // shifts per lane in the tiled kernels
 #define SM_P 8       // pixels per lane
@@ -90,6 +90,10 @@ int sm_fail(int code, const char *fmt, ...);
             return sm_fail(SM_ERR_HIP, "launch of %s failed: %s", name,       \
                            hipGetErrorString(e_));                            \
     } while (0)
+
+// sm_match_bs.hip (bit-sliced kernel; nullptr if not built for this window)
+const void *sm_bs_kernel_ptr(int n, bool fulld, bool ghost);
+int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);
 
 // sm_match.hip
 int sm_match_configure(sm_plan *plan);   // fills plan->kernel / plan->g

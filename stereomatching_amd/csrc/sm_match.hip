@@ -46,6 +46,7 @@
 
 #include <algorithm>
 #include <stdlib.h>
+#include <string.h>
 
 static_assert(SM_DSET == 16 && SM_P == 8, "pixel_winner / the key loop are written out for 16 x 8");
 
@@ -479,6 +480,17 @@ int sm_match_configure(sm_plan *plan)
     else if (g.n <= 9) kernel = SM_KERNEL_A;
     else if (g.n <= 16) kernel = SM_KERNEL_B;
     else kernel = SM_KERNEL_C;
+    // the bit-sliced kernel where it is built (common windows, D <= 512);
+    // SM_KERNEL=popcount keeps the general kernels (A/B testing)
+    {
+        int nl_bs = 1;
+        while (nl_bs * SM_DSET < D) nl_bs <<= 1;
+        const char *force = getenv("SM_KERNEL");
+        const bool want_bs = !(force && !strcmp(force, "popcount"));
+        if (want_bs && kernel != SM_KERNEL_GENERIC && nl_bs <= 32 &&
+            sm_bs_kernel_ptr(g.n, nl_bs * SM_DSET == D, plan->border == SM_GHOST))
+            kernel = SM_KERNEL_BS;
+    }
     plan->kernel = kernel;
 
     if (kernel == SM_KERNEL_GENERIC) {
@@ -498,12 +510,26 @@ int sm_match_configure(sm_plan *plan)
     int nl = 1, log2nl = 0;
     while (nl * SM_DSET < D) { nl <<= 1; log2nl++; }
     g.nl = nl; g.log2nl = log2nl;
-    g.runs = nl == 1 ? 64 : (nl <= 8 ? 32 : 256 / nl);
-    g.threads = g.runs * nl;
-    g.tw = g.runs * SM_P;
-    g.tiles_x = ceil_div(W, g.tw);
-    g.plw = (SM_PADT + g.tw + g.half + 31) / 32 + 1;
-    g.prw = (SM_PADT + g.tw + g.half + nl * SM_DSET + 31) / 32 + 1;
+    const bool bs = kernel == SM_KERNEL_BS;
+    int rows_words;          // LDS words per staged row
+    if (bs) {
+        // one wave per workgroup: 64/nl words of 32 pixels, nl shift-lanes each
+        g.runs = 64 / nl;
+        g.threads = 64;
+        g.tw = g.runs * 32;
+        g.tiles_x = ceil_div(W, g.tw);
+        g.plw = g.runs + 2;
+        g.prw = g.runs + (nl * SM_DSET + 31) / 32 + 4;
+        rows_words = g.plw + g.prw;
+    } else {
+        g.runs = nl == 1 ? 64 : (nl <= 8 ? 32 : 256 / nl);
+        g.threads = g.runs * nl;
+        g.tw = g.runs * SM_P;
+        g.tiles_x = ceil_div(W, g.tw);
+        g.plw = (SM_PADT + g.tw + g.half + 31) / 32 + 1;
+        g.prw = (SM_PADT + g.tw + g.half + nl * SM_DSET + 31) / 32 + 1;
+        rows_words = (g.plw + g.prw) * 3;     // plain + spread
+    }
 
     // ---- tile height.  Tall tiles amortise the n-1 warm-up rows, but the grid
     // should fill the chip's resident slots in whole rounds: a tail round with a
@@ -517,10 +543,11 @@ int sm_match_configure(sm_plan *plan)
             cus = prop.multiProcessorCount;
         if (const char *e = getenv("SM_TILE_H")) th_env = atoi(e);   // tuning / tests only
     }
-    const void *kfn = tiled_kernel_ptr(kernel, tiled_fulld(g), plan->border == SM_GHOST);
+    const void *kfn = bs ? sm_bs_kernel_ptr(g.n, tiled_fulld(g), plan->border == SM_GHOST)
+                         : tiled_kernel_ptr(kernel, tiled_fulld(g), plan->border == SM_GHOST);
     const double wps = g.threads / 256.0;            // waves per SIMD per workgroup
     const double warm = 0.4 * (g.n - 1) + 2.0;       // warm-up rows cost ~0.4 of an output row
-    auto lds_of = [&](int th) { return (th + g.n - 1) * (g.plw + g.prw) * 3 * 4; };
+    auto lds_of = [&](int th) { return (th + g.n - 1) * rows_words * 4; };
     int th = 0;
     double best_cost = 0;
     for (int c = 4; c <= 256; c++) {
@@ -547,16 +574,18 @@ int sm_match_configure(sm_plan *plan)
     g.tile_h = th;
     g.tiles_y = ceil_div(H, th);
     g.nsr = th + g.n - 1;
-    g.lds_bytes = g.nsr * (g.plw + g.prw) * 3 * 4;
-    g.ext_words = (g.tiles_x - 1) * (g.tw / 32) + g.prw;
+    g.lds_bytes = g.nsr * rows_words * 4;
+    g.ext_words = (g.tiles_x - 1) * (g.tw / 32) + g.prw + (bs ? 0 : 0);
     g.ext_rows = g.tiles_y * th + g.n - 1;
     g.ext_image_words = (long long)g.ext_words * g.ext_rows;
     g.vec_ok = (W % 4) == 0;
 
     snprintf(plan->describe, sizeof plan->describe,
-             "tiled kernel %c (n=%d, D=%d, %s): tile %dx%d px, %d threads "
+             "%s (n=%d, D=%d, %s): tile %dx%d px, %d threads "
              "(%d runs x %d shift-lanes), grid %dx%d, LDS %d B/wg, ext %dx%d words",
-             "ABC"[kernel], g.n, D, plan->border == SM_GHOST ? "ghost" : "toroidal",
+             bs ? "bit-sliced kernel" : kernel == SM_KERNEL_A ? "tiled kernel A"
+                : kernel == SM_KERNEL_B ? "tiled kernel B" : "tiled kernel C",
+             g.n, D, plan->border == SM_GHOST ? "ghost" : "toroidal",
              g.tw, g.tile_h, g.threads, g.runs, g.nl, g.tiles_x, g.tiles_y, g.lds_bytes,
              g.ext_words, g.ext_rows);
     return SM_OK;
@@ -580,6 +609,7 @@ int sm_match_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream
 {
     const MatchGeom &g = plan->g;
     switch (plan->kernel) {
+    case SM_KERNEL_BS: return sm_bs_launch(plan, pairs, d_web, d_best, st);
     case SM_KERNEL_A: launch_tiled<SM_KERNEL_A>(plan, pairs, d_web, d_best, st); break;
     case SM_KERNEL_B: launch_tiled<SM_KERNEL_B>(plan, pairs, d_web, d_best, st); break;
     case SM_KERNEL_C: launch_tiled<SM_KERNEL_C>(plan, pairs, d_web, d_best, st); break;

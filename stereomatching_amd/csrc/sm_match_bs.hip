@@ -1,0 +1,426 @@
+// sm_match_bs.hip -- the hot path, BIT-SLICED: match cost -> S x S window sum
+// -> masked score -> winner-take-all, 32 pixels per lane operation.
+//
+// Same contract as sm_match.hip (which remains the general kernel for window
+// sizes not instantiated here); same packed ext image as input.
+//
+// Why: on gfx950 only v_and/or/xor/add/sub/lshr/ashr/bitop3 issue at full
+// rate; v_bcnt, v_bfe, v_max, v_lshl*, v_cmp ... take twice as long
+// (tools/ubench_valu*.hip).  The popcount/max kernel is bound
+// by exactly those.  Here every number lives as BIT PLANES: plane k of a value
+// is a 32-bit word holding bit k of that value for 32 neighbouring pixels, and
+// all arithmetic is built from v_bitop3 / v_and / v_xor (full rate, 32 pixels
+// at a time):
+//   x_i   = L(x+i) ^ R(x+i+d)                      mismatch bit of window column i
+//   Hx    = sum_i x_i        carry-save adder tree  (N inputs -> HB planes)
+//   Sx   += Hx(new row) ; Sx -= Hx(old row)         ripple add / subtract on SB planes
+//   upd   = centre_match & (Sx <= B)                borrow chain of B - Sx
+//   B     = upd ? Sx : B ;  arg = upd ? d : arg     v_bitop3 selects
+// Scores are kept as MISMATCH counts: the reference's score is
+// (#valid window taps) - Sx and the tap count does not depend on the shift, so
+// "highest score, last shift wins" == "lowest Sx, last shift wins" (ascending
+// d with <=).  best = taps - B is formed when the planes are turned back into
+// integers.  B starts at all ones (2^SB - 1 > N*N), which doubles as the "no
+// shift matched" marker (-> web = D, best = 0; src/stereo.c:211-218).
+//
+// Lane = one 32-pixel word x DS = 16 shifts, marching down the tile with the
+// 16 x SB sum planes in VGPRs.  The shift range of a word is split over
+// nl = D/16 adjacent lanes, merged per row with DPP row operations on the
+// planes (lexicographic: lower Sx, then the lane holding the higher shifts).
+// After the merge each of the nl lanes turns 32/nl pixels back into integers
+// and stores them.
+
+#include "sm_internal.h"
+
+template <int IMM>
+__device__ __forceinline__ u32 bop(u32 a, u32 b, u32 c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, IMM);   // bit (a<<2|b<<1|c) of IMM
+}
+#define BOP_XOR3 0x96      // a ^ b ^ c
+#define BOP_MAJ 0xE8       // majority(a, b, c)
+#define BOP_BORROW 0x8E    // majority(~a, b, c): borrow out of a - b - c
+#define BOP_SEL 0xCA       // a ? b : c
+#define BOP_XOR_AND 0x28   // (a ^ b) & c
+#define BOP_UPD 0x41       // ~(a ^ b) & ~c
+
+__device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+constexpr int bits_for(int v) { int b = 0; while ((1 << b) <= v) b++; return b; }   // v < 2^b
+
+// ---------------------------------------------------------------------------
+// carry-save tree: N one-bit inputs -> their count on HB planes.  Everything
+// about the wiring is known at compile time; after unrolling only the
+// v_bitop3 / v_xor / v_and of the adders remain (5 full + 2 half adders for 9).
+// ---------------------------------------------------------------------------
+template <int N, int HB>
+__device__ __forceinline__ void count_bits(const u32 (&x)[N], u32 (&h)[HB])
+{
+    u32 q[2 * N + 2];          // wires of the current weight, used as a queue
+    int head = 0, tail = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) q[tail++] = x[i];
+#pragma unroll
+    for (int w = 0; w < HB; w++) {
+        u32 nx[N + 1];         // carries: wires of the next weight
+        int nn = 0;
+#pragma unroll
+        for (int it = 0; it < N; it++) {
+            if (tail - head >= 3) {
+                const u32 a = q[head], b = q[head + 1], c = q[head + 2];
+                head += 3;
+                q[tail++] = bop<BOP_XOR3>(a, b, c);
+                nx[nn++] = bop<BOP_MAJ>(a, b, c);
+            }
+        }
+        if (tail - head == 2) {
+            const u32 a = q[head], b = q[head + 1];
+            head += 2;
+            q[tail++] = a ^ b;
+            nx[nn++] = a & b;
+        }
+        h[w] = tail - head == 1 ? q[head] : 0u;
+        head = tail = 0;
+#pragma unroll
+        for (int i = 0; i < N + 1; i++)
+            if (i < nn) q[tail++] = nx[i];
+    }
+}
+
+// s += h  (s: SB planes, h: HB planes, HB <= SB; the sum is known to fit)
+template <int SB, int HB>
+__device__ __forceinline__ void add_planes(u32 (&s)[SB], const u32 (&h)[HB])
+{
+    u32 c = s[0] & h[0];
+    s[0] ^= h[0];
+#pragma unroll
+    for (int k = 1; k < SB; k++) {
+        if (k < HB) {
+            const u32 t = bop<BOP_XOR3>(s[k], h[k], c);
+            c = bop<BOP_MAJ>(s[k], h[k], c);
+            s[k] = t;
+        } else {
+            const u32 t = s[k] ^ c;
+            if (k + 1 < SB) c = s[k] & c;
+            s[k] = t;
+        }
+    }
+}
+
+// s -= h  (never negative)
+template <int SB, int HB>
+__device__ __forceinline__ void sub_planes(u32 (&s)[SB], const u32 (&h)[HB])
+{
+    u32 b = ~s[0] & h[0];
+    s[0] ^= h[0];
+#pragma unroll
+    for (int k = 1; k < SB; k++) {
+        if (k < HB) {
+            const u32 t = bop<BOP_XOR3>(s[k], h[k], b);
+            b = bop<BOP_BORROW>(s[k], h[k], b);
+            s[k] = t;
+        } else {
+            const u32 t = s[k] ^ b;
+            if (k + 1 < SB) b = ~s[k] & b;
+            s[k] = t;
+        }
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ u32 dpp(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// partner lane of merge step K (lane ^ (1 << K)) for K = 0..3 via DPP, 4/5 via
+// the LDS crossbar
+template <int K>
+__device__ __forceinline__ u32 from_partner(u32 v)
+{
+    if (K == 0) return dpp<0xB1>(v);            // quad_perm [1,0,3,2]
+    if (K == 1) return dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    if (K == 2) return dpp<0x141>(v);           // row_half_mirror: i <-> 7 - i
+    if (K == 3) return dpp<0x140>(v);           // row_mirror:      i <-> 15 - i
+    return (u32)__shfl_xor((int)v, 1 << K);
+}
+
+// ---------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------
+
+template <int N, bool FULLD, bool GHOST>
+__global__ __launch_bounds__(64) void k_match_bs(const u32 *__restrict__ ext,
+                                                 i32 *__restrict__ web, i32 *__restrict__ best,
+                                                 const MatchGeom g)
+{
+    constexpr int DS = SM_DSET;                 // 16 shifts per lane
+    constexpr int HALF = N / 2;
+    constexpr int HB = bits_for(N);             // planes of a horizontal count
+    constexpr int SB = bits_for(N * N);         // planes of a window count; 2^SB - 1 > N*N
+    constexpr int AB = 4;                       // planes of the in-lane shift index
+    constexpr int ABMAX = AB + 6;               // after merging up to 64 lanes
+    constexpr int NV = N + DS - 1;              // shifted views of the right row
+    static_assert((1 << SB) - 1 > N * N, "the all-ones marker must not be a real count");
+    static_assert(N + DS - 1 + 31 < 96, "right window must fit three words");
+
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.z;
+    const int tx0 = blockIdx.x * g.tw;
+    const int ty0 = blockIdx.y * g.tile_h;
+    const int plw = g.plw, prw = g.prw, nsr = g.nsr;
+    const u32 *extL = ext + (size_t)pair * 2 * g.ext_image_words;
+    const u32 *extR = extL + g.ext_image_words;
+    u32 *pL = lds;                  // [nsr][plw]
+    u32 *pR = pL + nsr * plw;       // [nsr][prw]
+
+    // ---- stage the tile's rows (+ window halo): coalesced dword row loads
+    {
+        const int wx0 = tx0 >> 5;
+        const int per_row = plw + prw;
+        for (int it = tid; it < nsr * per_row; it += 64) {
+            const int row = it / per_row, k = it - row * per_row;
+            const bool is_r = k >= plw;
+            const int kk = is_r ? k - plw : k;
+            const u32 v = (is_r ? extR : extL)[(size_t)(ty0 + row) * g.ext_words + wx0 + kk];
+            if (is_r) pR[row * prw + kk] = v; else pL[row * plw + kk] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- lane role
+    const int s = tid & (g.nl - 1);           // which 16 shifts
+    const int wi = tid >> g.log2nl;           // which 32-pixel word of the tile
+    const int d0 = s * DS;
+    const int x0 = tx0 + 32 * wi;
+    // bit offsets in a staged row (bit = SM_PADT + tile-local x)
+    const int bL = SM_PADT + 32 * wi - HALF, bR = bL + d0;
+    const int wL = bL >> 5, shL = bL & 31, wR = bR >> 5, shR = bR & 31;
+    const int bRc = SM_PADT + 32 * wi + d0;
+    const int wRc = bRc >> 5, shRc = bRc & 31;
+    const int wLc = 1 + wi;
+
+    // ghost: validity of the window columns (bit i of cv = column x0 - HALF + i)
+    u32 cvv[N];
+    if (GHOST) {
+        u32 c0 = 0, c1 = 0;
+        for (int i = 0; i < 64; i++) {
+            const int x = x0 - HALF + i;
+            if (x >= 0 && x < g.w) { if (i < 32) c0 |= 1u << i; else c1 |= 1u << (i - 32); }
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) cvv[i] = i ? alignbit(c1, c0, i) : c0;
+    }
+    // shifts >= D of this lane never match
+    u32 dvalid = 0xffffu;
+    if (!FULLD) {
+        const int dlim = g.D - d0;
+        dvalid = dlim >= DS ? 0xffffu : (dlim <= 0 ? 0u : ((1u << dlim) - 1u));
+    }
+
+    u32 S[DS][SB];
+#pragma unroll
+    for (int dd = 0; dd < DS; dd++)
+#pragma unroll
+        for (int k = 0; k < SB; k++) S[dd][k] = 0;
+
+    // one window row into (add) or out of (sub) all 16 sums
+    auto slide = [&](int srow, bool add) {
+        const u32 *rl = pL + srow * plw + wL;
+        const u32 *rr = pR + srow * prw + wR;
+        const u32 l0 = alignbit(rl[1], rl[0], shL), l1 = alignbit(rl[2], rl[1], shL);
+        u32 rw[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) rw[k] = alignbit(rr[k + 1], rr[k], shR);
+        u32 lv[N], rv[NV];
+#pragma unroll
+        for (int i = 0; i < N; i++) lv[i] = i ? alignbit(l1, l0, i) : l0;
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+            rv[j] = (j & 31) ? alignbit(rw[(j >> 5) + 1], rw[j >> 5], j & 31) : rw[j >> 5];
+#pragma unroll
+        for (int dd = 0; dd < DS; dd++) {
+            u32 x[N], h[HB];
+#pragma unroll
+            for (int i = 0; i < N; i++)
+                x[i] = GHOST ? bop<BOP_XOR_AND>(lv[i], rv[i + dd], cvv[i]) : (lv[i] ^ rv[i + dd]);
+            count_bits<N, HB>(x, h);
+            if (add) add_planes<SB, HB>(S[dd], h); else sub_planes<SB, HB>(S[dd], h);
+        }
+    };
+
+    const int rows_out = min(g.tile_h, g.h - ty0);
+    const int steps = rows_out + N - 1;
+    for (int e = 0; e < steps; e++) {
+        // staged row e is image row ty0 - HALF + e; ghost rows outside the image
+        // hold no valid tap: nothing to add or remove
+        {
+            const int y_new = ty0 - HALF + e;
+            if (!GHOST || (y_new >= 0 && y_new < g.h)) slide(e, true);
+            if (e >= N) {
+                const int y_old = y_new - N;
+                if (!GHOST || (y_old >= 0 && y_old < g.h)) slide(e - N, false);
+            }
+        }
+        if (e < N - 1) continue;
+
+        // ---- winner-take-all of output row t over this lane's 16 shifts
+        const int t = e - (N - 1);
+        const int y = ty0 + t;
+        const u32 lc = pL[(t + HALF) * plw + wLc];
+        const u32 *rrc = pR + (t + HALF) * prw + wRc;
+        const u32 rc0 = alignbit(rrc[1], rrc[0], shRc), rc1 = alignbit(rrc[2], rrc[1], shRc);
+
+        u32 B[SB], arg[ABMAX];
+#pragma unroll
+        for (int k = 0; k < SB; k++) B[k] = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < ABMAX; k++) arg[k] = 0;
+#pragma unroll
+        for (int dd = 0; dd < DS; dd++) {
+            const u32 rcd = dd ? alignbit(rc1, rc0, dd) : rc0;
+            u32 bw = 0;                                  // borrow of B - S: 1 <=> B < S
+#pragma unroll
+            for (int k = 0; k < SB; k++) bw = bop<BOP_BORROW>(B[k], S[dd][k], bw);
+            u32 upd = bop<BOP_UPD>(lc, rcd, bw);         // centre matches and S <= B
+            if (!FULLD) upd &= (u32)__builtin_amdgcn_sbfe((int)dvalid, dd, 1);
+#pragma unroll
+            for (int k = 0; k < SB; k++) B[k] = bop<BOP_SEL>(upd, S[dd][k], B[k]);
+#pragma unroll
+            for (int k = 0; k < AB; k++) {
+                if ((dd >> k) & 1) arg[k] |= upd; else arg[k] &= ~upd;
+            }
+        }
+
+        // ---- merge the nl lanes of this word: lower count wins, on a tie the lane
+        // with the higher shifts (partner's bit K of the lane index set)
+#define SM_MERGE(K)                                                                    \
+        if (g.nl > (1 << K)) {                                                         \
+            u32 pb[SB], pa[AB + K];                                                    \
+            _Pragma("unroll") for (int k = 0; k < SB; k++) pb[k] = from_partner<K>(B[k]);      \
+            _Pragma("unroll") for (int k = 0; k < AB + K; k++) pa[k] = from_partner<K>(arg[k]); \
+            const u32 mine_high = (s >> K) & 1 ? 0xffffffffu : 0u;                     \
+            u32 bw = mine_high;          /* borrow-in 1: partner - mine - 1 < 0 <=> partner <= mine */ \
+            bw = ~bw;                    /* partner is the high one iff I am not */   \
+            _Pragma("unroll") for (int k = 0; k < SB; k++) bw = bop<BOP_BORROW>(pb[k], B[k], bw); \
+            const u32 take = bw;                                                       \
+            _Pragma("unroll") for (int k = 0; k < SB; k++) B[k] = bop<BOP_SEL>(take, pb[k], B[k]); \
+            _Pragma("unroll") for (int k = 0; k < AB + K; k++) arg[k] = bop<BOP_SEL>(take, pa[k], arg[k]); \
+            arg[AB + K] = take ^ mine_high;   /* partner's bit K = ~mine */          \
+        }
+        SM_MERGE(0) SM_MERGE(1) SM_MERGE(2) SM_MERGE(3) SM_MERGE(4) SM_MERGE(5)
+#undef SM_MERGE
+
+        // ---- planes -> integers.  After the merge all nl lanes of a word hold the
+        // same planes; lane s converts pixels [s*per, s*per + per), per = 32/nl.
+        if (y < g.h) {
+            const int per = 32 >> g.log2nl;
+            const int p0 = s * per;
+            if (per == 4 && g.D <= 256 && SB <= 8) {
+                // 4 pixels at once.  nib = the 4 bits of a plane; nib * 0x204081 puts
+                // copy j of the nibble at bit 7j, so bit 8q holds pixel q's bit:
+                // & 0x01010101 leaves one byte per pixel; byte lanes then add up planes.
+                u32 ab = 0, bb = 0, allone = 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < SB; k++) {
+                    const u32 nib = (B[k] >> p0) & 15u;
+                    bb += (__umul24(nib, 0x204081u) & 0x01010101u) << k;
+                    allone &= B[k];
+                }
+#pragma unroll
+                for (int k = 0; k < AB + 4; k++) {       // D <= 256: at most 8 planes
+                    const u32 nib = (arg[k] >> p0) & 15u;
+                    ab += (__umul24(nib, 0x204081u) & 0x01010101u) << k;
+                }
+                const u32 none = __umul24((allone >> p0) & 15u, 0x204081u) & 0x01010101u;   // 1 = no match
+                i32 wv[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool no = (none >> (8 * q)) & 1u;
+                    int taps = N * N;
+                    if (GHOST) {
+                        const int x = x0 + p0 + q;
+                        const int cols = min(g.w - 1, x + HALF) - max(0, x - HALF) + 1;
+                        const int rws = min(g.h - 1, y + HALF) - max(0, y - HALF) + 1;
+                        taps = cols * rws;
+                    }
+                    wv[q] = no ? g.D : (i32)((ab >> (8 * q)) & 255u) + 1;
+                    bv[q] = no ? 0 : taps - (i32)((bb >> (8 * q)) & 255u);
+                }
+                const int x = x0 + p0;
+                const size_t o = ((size_t)pair * g.h + y) * g.w + x;
+                if (g.vec_ok && x + 4 <= g.w) {
+                    *reinterpret_cast<int4 *>(web + o) = make_int4(wv[0], wv[1], wv[2], wv[3]);
+                    if (best) *reinterpret_cast<int4 *>(best + o) = make_int4(bv[0], bv[1], bv[2], bv[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (x + q < g.w) {
+                            web[o + q] = wv[q];
+                            if (best) best[o + q] = bv[q];
+                        }
+                }
+            } else {
+                for (int q = 0; q < per; q++) {
+                    const int p = p0 + q;
+                    const int x = x0 + p;
+                    if (x >= g.w) break;
+                    u32 bsum = 0, a = 0;
+#pragma unroll
+                    for (int k = 0; k < SB; k++) bsum |= ((B[k] >> p) & 1u) << k;
+#pragma unroll
+                    for (int k = 0; k < ABMAX; k++) a |= ((arg[k] >> p) & 1u) << k;
+                    const bool any = bsum != (1u << SB) - 1u;
+                    int taps = N * N;
+                    if (GHOST) {
+                        const int cols = min(g.w - 1, x + HALF) - max(0, x - HALF) + 1;
+                        const int rws = min(g.h - 1, y + HALF) - max(0, y - HALF) + 1;
+                        taps = cols * rws;
+                    }
+                    const size_t o = ((size_t)pair * g.h + y) * g.w + x;
+                    web[o] = any ? (i32)a + 1 : g.D;
+                    if (best) best[o] = any ? taps - (i32)bsum : 0;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+template <int N>
+static const void *bs_ptr(bool fulld, bool ghost)
+{
+    return fulld ? (ghost ? (const void *)k_match_bs<N, true, true> : (const void *)k_match_bs<N, true, false>)
+                 : (ghost ? (const void *)k_match_bs<N, false, true> : (const void *)k_match_bs<N, false, false>);
+}
+
+const void *sm_bs_kernel_ptr(int n, bool fulld, bool ghost)
+{
+    switch (n) {
+    case 5: return bs_ptr<5>(fulld, ghost);
+    case 7: return bs_ptr<7>(fulld, ghost);
+    case 9: return bs_ptr<9>(fulld, ghost);
+    case 11: return bs_ptr<11>(fulld, ghost);
+    default: return nullptr;
+    }
+}
+
+int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
+{
+    const MatchGeom &g = plan->g;
+    const void *fn = sm_bs_kernel_ptr(g.n, g.nl * SM_DSET == g.D, plan->border == SM_GHOST);
+    if (!fn) return sm_fail(SM_ERR_ARG, "bit-sliced kernel not built for n = %d", g.n);
+    void *args[] = {(void *)&plan->d_ext, (void *)&d_web, (void *)&d_best, (void *)&g};
+    hipError_t e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(g.threads), args,
+                                   g.lds_bytes, st);
+    if (e != hipSuccess)
+        return sm_fail(SM_ERR_HIP, "launch of k_match_bs failed: %s", hipGetErrorString(e));
+    return SM_OK;
+}
