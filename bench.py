@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--with-best", action="store_true", help="also write score_best")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the CPU-baseline band")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap the edge kernel of step i+1 with the match kernel of step i "
+                         "(sm_plan_set_pipelined; measured: no net gain, both kernels are VALU-heavy)")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region, collect the maps on rank 0 over RCCL and time it")
     return ap.parse_args()
@@ -119,31 +122,31 @@ def main():
     p_web = C.c_void_p(web.data_ptr())
     p_best = C.c_void_p(best.data_ptr()) if best is not None else C.c_void_p(0)
 
-    def step(ev=None):
-        check(lib.sm_find_edges(plan._h, p_l, p_r, args.threshold, pairs, None, None, stream))
-        if ev:
-            ev[0].record()
-        check(lib.sm_match_wta(plan._h, pairs, p_web, p_best, stream))
-        if ev:
-            ev[1].record()
+    # Optional: the inputs are resident and complete, so consecutive steps may overlap
+    # (edge kernel of step i+1 beside the match kernel of step i on the plan's internal
+    # stream).  Every step still does all its work.
+    plan.set_pipelined(args.pipeline)
+
+    def step():
+        check(lib.sm_run(plan._h, p_l, p_r, args.threshold, pairs, p_web, p_best, stream))
 
     for _ in range(args.warmup):
         step()
-    # HIP events around the dominant kernel, on the stream it is launched on
-    # (torch's current stream is the one handed to the C ABI)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
-
     torch.cuda.synchronize(dev)
+    # HIP events around the dominant kernel, recorded by the library on the stream
+    # the kernel is launched on, over the timed region itself
+    plan.time_kernels(args.steps)
+
     shard.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events[i])
+        step()
     torch.cuda.synchronize(dev)
     shard.barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
 
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
+    kernel_ms, n_timed = plan.kernel_ms()
+    assert n_timed == args.steps
     units_per_step = float(w) * h * d * pairs                      # pixel-disparities / rank
     value = units_per_step * world * args.steps / elapsed / 1e6
 
@@ -160,7 +163,7 @@ def main():
         return
 
     acv = A_CV_BYTES * units_per_step / (kernel_ms * 1e-3) / 1e9   # GB/s
-    amin_kernel = (4.0 * w * h * pairs + plan.workspace_bytes() / plan.max_pairs * pairs) \
+    amin_kernel = (4.0 * w * h * pairs + plan.workspace_bytes() / 2 / plan.max_pairs * pairs) \
         / (kernel_ms * 1e-3) / 1e9
     amin_step = A_MIN_BYTES * w * h * pairs / (elapsed / args.steps) / 1e9
     traffic = None
@@ -191,10 +194,11 @@ def main():
                         f"{pairs} pair(s)/GPU/step; edges + fused match/aggregate/WTA -> web",
             "kernel": plan.describe(),
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
+            "pipelined": args.pipeline,
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_match_wta",
+            "kernel": "k_match_bs" if "bit-sliced" in plan.describe() else "k_match_wta",
             "achieved": round(acv, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

@@ -106,6 +106,24 @@ int sm_load_edges(sm_plan *plan, const uint8_t *d_edges_left,
 int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d_best,
                  void *stream);
 
+/* Let consecutive sm_run calls overlap: with the flag set, sm_run launches its
+ * edge detection on an internal stream into the other half of a double-buffered
+ * workspace, so that it runs beside the (VALU-bound) match kernel of the
+ * PREVIOUS call; the match kernel itself still goes to `stream`, and
+ * synchronising `stream` still means "all results are there".  The caller
+ * promises that the input images handed to sm_run are complete in memory when
+ * sm_run is called (it no longer orders them behind earlier work on `stream`).
+ * Off by default.                                                             */
+int sm_plan_set_pipelined(sm_plan *plan, int enabled);
+
+/* Measurement aid: with capacity > 0 the plan brackets each of the next
+ * `capacity` sm_match_wta / sm_run match launches with HIP events ON THE STREAM
+ * THE KERNEL IS LAUNCHED ON (capacity 0 turns it off and frees the events).
+ * sm_plan_kernel_ms synchronises those events and returns the mean duration
+ * in milliseconds and the number of launches recorded since the last reset.  */
+int sm_plan_time_kernels(sm_plan *plan, int capacity);
+int sm_plan_kernel_ms(sm_plan *plan, double *mean_ms, int *launches);
+
 /* steps 1 + 2 back to back: uint8 pairs in, web out */
 int sm_run(sm_plan *plan, const uint8_t *d_gray_left,
            const uint8_t *d_gray_right, double threshold, int pairs,

@@ -430,6 +430,8 @@ __global__ __launch_bounds__(256) void k_contour(const i32 *__restrict__ web,
 // C ABI
 // ---------------------------------------------------------------------------
 
+static void free_timing(sm_plan *plan);
+
 static int use_device(int device)
 {
     SM_HIP(hipSetDevice(device));
@@ -514,13 +516,26 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
     if (rc) { free(p); return rc; }
 
     p->ext_bytes = (size_t)max_pairs * 2 * (size_t)p->g.ext_image_words * sizeof(u32);
-    hipError_t e = hipMalloc((void **)&p->d_ext, p->ext_bytes);
+    hipError_t e = hipMalloc((void **)&p->d_ext_buf[0], p->ext_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_ext_buf[1], p->ext_bytes);
+    if (e == hipSuccess) e = hipMemset(p->d_ext_buf[1], 0, p->ext_bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->edge_stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipEventCreateWithFlags(&p->ev_edges[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_free[b], hipEventDisableTiming);
+    }
+    p->d_ext = p->d_ext_buf[0];
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flags, 4 * sizeof(i32));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_edge_tab, 768 * sizeof(u32));
     if (e == hipSuccess) e = hipMemset(p->d_ext, 0, p->ext_bytes);
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(i32));
     if (e != hipSuccess) {
-        if (p->d_ext) (void)hipFree(p->d_ext);
+        for (int b = 0; b < 2; b++) {
+            if (p->d_ext_buf[b]) (void)hipFree(p->d_ext_buf[b]);
+            if (p->ev_edges[b]) (void)hipEventDestroy(p->ev_edges[b]);
+            if (p->ev_free[b]) (void)hipEventDestroy(p->ev_free[b]);
+        }
+        if (p->edge_stream) (void)hipStreamDestroy(p->edge_stream);
         if (p->d_flags) (void)hipFree(p->d_flags);
         if (p->d_edge_tab) (void)hipFree(p->d_edge_tab);
         free(p);
@@ -535,7 +550,14 @@ extern "C" void sm_plan_destroy(sm_plan *plan)
 {
     if (!plan) return;
     (void)hipSetDevice(plan->device);
-    (void)hipFree(plan->d_ext);
+    (void)hipStreamSynchronize(plan->edge_stream);
+    free_timing(plan);
+    for (int b = 0; b < 2; b++) {
+        (void)hipFree(plan->d_ext_buf[b]);
+        (void)hipEventDestroy(plan->ev_edges[b]);
+        (void)hipEventDestroy(plan->ev_free[b]);
+    }
+    (void)hipStreamDestroy(plan->edge_stream);
     (void)hipFree(plan->d_flags);
     (void)hipFree(plan->d_edge_tab);
     free(plan);
@@ -545,7 +567,7 @@ extern "C" const char *sm_plan_describe(const sm_plan *plan) { return plan ? pla
 
 extern "C" size_t sm_plan_workspace_bytes(const sm_plan *plan)
 {
-    return plan ? plan->ext_bytes + 4 * sizeof(i32) : 0;
+    return plan ? 2 * plan->ext_bytes + 4 * sizeof(i32) + 768 * sizeof(u32) : 0;
 }
 
 static int check_plan_pairs(const sm_plan *plan, int pairs, const char *who)
@@ -658,13 +680,88 @@ extern "C" int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d
         return sm_fail(SM_ERR_ARG, "sm_match_wta: %d pairs requested but edges of only %d are loaded "
                        "(call sm_find_edges or sm_load_edges first)", pairs, plan->pairs_loaded);
     SM_TRY(use_device(plan->device));
-    return sm_match_launch(plan, pairs, d_web, d_best, (hipStream_t)stream);
+    const bool timed = plan->timing_n < plan->timing_cap;
+    if (timed) SM_HIP(hipEventRecord(plan->t_begin[plan->timing_n], (hipStream_t)stream));
+    SM_TRY(sm_match_launch(plan, pairs, d_web, d_best, (hipStream_t)stream));
+    if (timed) SM_HIP(hipEventRecord(plan->t_end[plan->timing_n++], (hipStream_t)stream));
+    // a later pipelined sm_run must not overwrite this buffer before the launch has read it
+    SM_HIP(hipEventRecord(plan->ev_free[plan->cur], (hipStream_t)stream));
+    plan->ev_free_set[plan->cur] = 1;
+    return SM_OK;
+}
+
+static void free_timing(sm_plan *plan)
+{
+    for (int i = 0; i < plan->timing_cap; i++) {
+        (void)hipEventDestroy(plan->t_begin[i]);
+        (void)hipEventDestroy(plan->t_end[i]);
+    }
+    free(plan->t_begin);
+    free(plan->t_end);
+    plan->t_begin = plan->t_end = nullptr;
+    plan->timing_cap = plan->timing_n = 0;
+}
+
+extern "C" int sm_plan_time_kernels(sm_plan *plan, int capacity)
+{
+    if (!plan || capacity < 0 || capacity > (1 << 20))
+        return sm_fail(SM_ERR_ARG, "sm_plan_time_kernels: bad argument");
+    SM_TRY(use_device(plan->device));
+    if (capacity == plan->timing_cap) { plan->timing_n = 0; return SM_OK; }
+    free_timing(plan);
+    if (capacity == 0) return SM_OK;
+    plan->t_begin = (hipEvent_t *)calloc(capacity, sizeof(hipEvent_t));
+    plan->t_end = (hipEvent_t *)calloc(capacity, sizeof(hipEvent_t));
+    if (!plan->t_begin || !plan->t_end) return sm_fail(SM_ERR_NOMEM, "error: out of memory");
+    for (int i = 0; i < capacity; i++) {
+        SM_HIP(hipEventCreate(&plan->t_begin[i]));
+        SM_HIP(hipEventCreate(&plan->t_end[i]));
+        plan->timing_cap = i + 1;
+    }
+    return SM_OK;
+}
+
+extern "C" int sm_plan_kernel_ms(sm_plan *plan, double *mean_ms, int *launches)
+{
+    if (!plan || !mean_ms || !launches) return sm_fail(SM_ERR_ARG, "sm_plan_kernel_ms: NULL argument");
+    SM_TRY(use_device(plan->device));
+    double sum = 0;
+    for (int i = 0; i < plan->timing_n; i++) {
+        float ms = 0;
+        SM_HIP(hipEventSynchronize(plan->t_end[i]));
+        SM_HIP(hipEventElapsedTime(&ms, plan->t_begin[i], plan->t_end[i]));
+        sum += ms;
+    }
+    *launches = plan->timing_n;
+    *mean_ms = plan->timing_n ? sum / plan->timing_n : 0.0;
+    return SM_OK;
+}
+
+extern "C" int sm_plan_set_pipelined(sm_plan *plan, int enabled)
+{
+    if (!plan) return sm_fail(SM_ERR_ARG, "sm_plan_set_pipelined: plan is NULL");
+    plan->pipelined = enabled != 0;
+    return SM_OK;
 }
 
 extern "C" int sm_run(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
                       double threshold, int pairs, int32_t *d_web, int32_t *d_best, void *stream)
 {
-    SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, stream));
+    if (!plan || !plan->pipelined) {
+        SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, stream));
+        return sm_match_wta(plan, pairs, d_web, d_best, stream);
+    }
+    // pipelined: edges of this call on the internal stream, into the buffer the
+    // previous call's match is NOT reading
+    SM_TRY(use_device(plan->device));
+    const int b = plan->cur ^ 1;
+    if (plan->ev_free_set[b]) SM_HIP(hipStreamWaitEvent(plan->edge_stream, plan->ev_free[b], 0));
+    plan->cur = b;
+    plan->d_ext = plan->d_ext_buf[b];
+    SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr,
+                         (void *)plan->edge_stream));
+    SM_HIP(hipEventRecord(plan->ev_edges[b], plan->edge_stream));
+    SM_HIP(hipStreamWaitEvent((hipStream_t)stream, plan->ev_edges[b], 0));
     return sm_match_wta(plan, pairs, d_web, d_best, stream);
 }
 

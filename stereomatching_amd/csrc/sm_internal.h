@@ -47,6 +47,7 @@ struct MatchGeom {
     int tile_h;          // output rows per workgroup
     int tw;              // output columns per workgroup (= 8 * runs)
     int runs;            // pixel runs (of 8) per workgroup
+    int ds;              // shifts per lane (16; 8 or 16 in the bit-sliced kernel)
     int nl, log2nl;      // lanes that split the shift range of one run
     int threads;         // runs * nl
     int plw, prw;        // words per staged LDS row, left / right
@@ -61,8 +62,18 @@ struct sm_plan {
     int width, height, num_shifts, square_width, border, max_pairs;
     int kernel;          // SM_KERNEL_*
     MatchGeom g;
-    u32 *d_ext;          // packed edge images
-    size_t ext_bytes;
+    u32 *d_ext;          // packed edge images: the buffer in use (one of d_ext_buf)
+    u32 *d_ext_buf[2];   // double buffer, so that sm_run can pipeline consecutive calls
+    size_t ext_bytes;    // of one buffer
+    int cur;             // index of d_ext in d_ext_buf
+    int pipelined;       // sm_plan_set_pipelined
+    hipStream_t edge_stream;     // internal: edge detection of call i+1 beside the match of call i
+    hipEvent_t ev_edges[2];      // edges written into buffer b
+    hipEvent_t ev_free[2];       // last match reading buffer b has finished
+    int ev_free_set[2];
+    // optional timing of the match launches (sm_plan_time_kernels)
+    int timing_cap, timing_n;
+    hipEvent_t *t_begin, *t_end;
     i32 *d_flags;        // [0] = zero-interval flag, [1] = has-zero scratch,
                          // [2] = edge table is not of threshold form
     u32 *d_edge_tab;     // 766 x {lo | hi << 16}: edge iff sb <= lo || sb >= hi
@@ -92,7 +103,7 @@ int sm_fail(int code, const char *fmt, ...);
     } while (0)
 
 // sm_match_bs.hip (bit-sliced kernel; nullptr if not built for this window)
-const void *sm_bs_kernel_ptr(int n, bool fulld, bool ghost);
+const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost);
 int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);
 
 // sm_match.hip

@@ -45,6 +45,7 @@
 #include "sm_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <stdlib.h>
 #include <string.h>
 
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256) void k_match_wta_generic(const u32 *__restrict
 
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-static bool tiled_fulld(const MatchGeom &g) { return g.nl * SM_DSET == g.D; }
+static bool tiled_fulld(const MatchGeom &g) { return g.nl * g.ds == g.D; }
 
 static const void *tiled_kernel_ptr(int mode, bool fulld, bool ghost)
 {
@@ -482,13 +483,14 @@ int sm_match_configure(sm_plan *plan)
     else kernel = SM_KERNEL_C;
     // the bit-sliced kernel where it is built (common windows, D <= 512);
     // SM_KERNEL=popcount keeps the general kernels (A/B testing)
+    const bool ghost = plan->border == SM_GHOST;
+    auto nl_for = [&](int ds, int &log2nl) { int nl = 1; log2nl = 0; while (nl * ds < D) { nl <<= 1; log2nl++; } return nl; };
     {
-        int nl_bs = 1;
-        while (nl_bs * SM_DSET < D) nl_bs <<= 1;
         const char *force = getenv("SM_KERNEL");
         const bool want_bs = !(force && !strcmp(force, "popcount"));
-        if (want_bs && kernel != SM_KERNEL_GENERIC && nl_bs <= 32 &&
-            sm_bs_kernel_ptr(g.n, nl_bs * SM_DSET == D, plan->border == SM_GHOST))
+        int l2;
+        if (want_bs && kernel != SM_KERNEL_GENERIC && nl_for(16, l2) <= 32 &&
+            sm_bs_kernel_ptr(g.n, 16, true, ghost))
             kernel = SM_KERNEL_BS;
     }
     plan->kernel = kernel;
@@ -499,7 +501,7 @@ int sm_match_configure(sm_plan *plan)
         g.ext_words = (g.pad_l + W + g.half + D + 31) / 32 + 2;
         g.ext_rows = H + 2 * g.half;
         g.ext_image_words = (long long)g.ext_words * g.ext_rows;
-        g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = 0;
+        g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = g.ds = 0;
         g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = 0;
         snprintf(plan->describe, sizeof plan->describe,
                  "generic kernel (n=%d, D=%d): 1 lane/pixel, direct window sums", g.n, D);
@@ -507,86 +509,109 @@ int sm_match_configure(sm_plan *plan)
     }
 
     g.pad_l = SM_PADT;
-    int nl = 1, log2nl = 0;
-    while (nl * SM_DSET < D) { nl <<= 1; log2nl++; }
-    g.nl = nl; g.log2nl = log2nl;
     const bool bs = kernel == SM_KERNEL_BS;
-    int rows_words;          // LDS words per staged row
-    if (bs) {
-        // one wave per workgroup: 64/nl words of 32 pixels, nl shift-lanes each
-        g.runs = 64 / nl;
-        g.threads = 64;
-        g.tw = g.runs * 32;
-        g.tiles_x = ceil_div(W, g.tw);
-        g.plw = g.runs + 2;
-        g.prw = g.runs + (nl * SM_DSET + 31) / 32 + 4;
-        rows_words = g.plw + g.prw;
-    } else {
-        g.runs = nl == 1 ? 64 : (nl <= 8 ? 32 : 256 / nl);
-        g.threads = g.runs * nl;
-        g.tw = g.runs * SM_P;
-        g.tiles_x = ceil_div(W, g.tw);
-        g.plw = (SM_PADT + g.tw + g.half + 31) / 32 + 1;
-        g.prw = (SM_PADT + g.tw + g.half + nl * SM_DSET + 31) / 32 + 1;
-        rows_words = (g.plw + g.prw) * 3;     // plain + spread
-    }
-
-    // ---- tile height.  Tall tiles amortise the n-1 warm-up rows, but the grid
-    // should fill the chip's resident slots in whole rounds: a tail round with a
-    // third of the CUs busy costs as much as a full one.  Model: a workgroup
-    // puts threads/256 waves on each SIMD; a SIMD issues one wave-instruction
-    // per 2 cycles, a single wave at most one per 4; rounds run back to back.
-    int cus = 256, th_env = 0;
+    int cus = 256, th_env = 0, ds_env = 0;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
         if (const char *e = getenv("SM_TILE_H")) th_env = atoi(e);   // tuning / tests only
+        if (const char *e = getenv("SM_DS")) ds_env = atoi(e);
     }
-    const void *kfn = bs ? sm_bs_kernel_ptr(g.n, tiled_fulld(g), plan->border == SM_GHOST)
-                         : tiled_kernel_ptr(kernel, tiled_fulld(g), plan->border == SM_GHOST);
-    const double wps = g.threads / 256.0;            // waves per SIMD per workgroup
-    const double warm = 0.4 * (g.n - 1) + 2.0;       // warm-up rows cost ~0.4 of an output row
-    auto lds_of = [&](int th) { return (th + g.n - 1) * rows_words * 4; };
-    int th = 0;
-    double best_cost = 0;
-    for (int c = 4; c <= 256; c++) {
-        if (c > H && c != 4) break;
-        const int cand = std::min(c, H);
-        if (lds_of(cand) > 64 * 1024) break;
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, g.threads, lds_of(cand)) != hipSuccess
-            || per_cu < 1)
-            per_cu = 1;
-        const long long tiles = (long long)g.tiles_x * ceil_div(H, cand) * plan->max_pairs;
-        const long long slots = (long long)cus * per_cu;
-        double cost = 0;
-        for (long long left = tiles; left > 0; left -= slots) {
-            const long long m = std::min(left, slots);
-            const double k = (double)((m + cus - 1) / cus) * wps;   // waves per SIMD this round
-            cost += (cand + warm) * std::max(4.0, 2.0 * k);
+
+    // ---- geometry for `ds` shifts per lane, with the tile height chosen by a cost
+    // model.  Tall tiles amortise the n-1 warm-up rows, but the grid should fill the
+    // chip's resident slots in whole rounds: a tail round with a third of the CUs busy
+    // costs as much as a full one.  Model: a workgroup puts threads/256 waves on each
+    // SIMD; a SIMD issues one wave-instruction per 2 cycles, a single wave at most one
+    // per 4; rounds run back to back; the work of a lane-row is proportional to ds.
+    auto configure = [&](int ds, MatchGeom &o, int &rows_words_o) -> double {
+        o = g;
+        o.ds = ds;
+        o.nl = nl_for(ds, o.log2nl);
+        int rows_words;
+        if (bs) {
+            // one wave per workgroup: 64/nl words of 32 pixels, nl shift-lanes each
+            o.runs = 64 / o.nl;
+            o.threads = 64;
+            o.tw = o.runs * 32;
+            o.plw = o.runs + 2;
+            o.prw = o.runs + (o.nl * ds + 31) / 32 + 4;
+            rows_words = o.plw + o.prw;
+        } else {
+            o.runs = o.nl == 1 ? 64 : (o.nl <= 8 ? 32 : 256 / o.nl);
+            o.threads = o.runs * o.nl;
+            o.tw = o.runs * SM_P;
+            o.plw = (SM_PADT + o.tw + o.half + 31) / 32 + 1;
+            o.prw = (SM_PADT + o.tw + o.half + o.nl * ds + 31) / 32 + 1;
+            rows_words = (o.plw + o.prw) * 3;     // plain + spread
         }
-        if (th == 0 || cost < best_cost * 0.999) { th = cand; best_cost = cost; }
+        rows_words_o = rows_words;
+        o.tiles_x = ceil_div(W, o.tw);
+        const bool fulld = o.nl * ds == D;
+        const void *kfn = bs ? sm_bs_kernel_ptr(o.n, ds, fulld, ghost) : tiled_kernel_ptr(kernel, fulld, ghost);
+        const double wps = o.threads / 256.0;            // waves per SIMD per workgroup
+        const double warm = (bs ? 0.35 : 0.4) * (o.n - 1) + 1.0;   // warm-up rows are cheaper than output rows
+        // lane-row work relative to ds = 16: the per-row shared views and one more merge level
+        const double work = ds == 16 ? 1.0 : 0.5 * 1.10;
+        auto lds_of = [&](int th) { return (th + o.n - 1) * rows_words * 4; };
+        int th = 0;
+        double best_cost = 0;
+        for (int c = 4; c <= 256; c++) {
+            if (c > H && c != 4) break;
+            const int cand = std::min(c, H);
+            if (lds_of(cand) > 64 * 1024) break;
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, o.threads, lds_of(cand)) != hipSuccess
+                || per_cu < 1)
+                per_cu = 1;
+            const long long tiles = (long long)o.tiles_x * ceil_div(H, cand) * plan->max_pairs;
+            const long long slots = (long long)cus * per_cu;
+            double cost = 0;
+            for (long long left = tiles; left > 0; left -= slots) {
+                const long long m = std::min(left, slots);
+                // the busiest SIMD of this round hosts j waves; measured (PMC): one wave
+                // alone retires an instruction every ~5.5 cycles, two co-resident waves
+                // progress almost as fast each, beyond that they share ~2.5 cycles/instr
+                const long long wg_per_cu = (m + cus - 1) / cus;
+                const int j = std::max(1, (int)std::ceil((double)wg_per_cu * wps - 1e-9));
+                cost += (cand + warm) * work * std::max(5.5, 2.5 * j);
+            }
+            if (th == 0 || cost < best_cost * 0.999) { th = cand; best_cost = cost; }
+        }
+        if (th == 0) th = 1;
+        if (th_env > 0) th = std::min(th_env, H);
+        while (lds_of(th) > 64 * 1024 && th > 1) th--;
+        o.tile_h = th;
+        o.tiles_y = ceil_div(H, th);
+        o.nsr = th + o.n - 1;
+        o.lds_bytes = o.nsr * rows_words * 4;
+        o.ext_words = (o.tiles_x - 1) * (o.tw / 32) + o.prw;
+        o.ext_rows = o.tiles_y * th + o.n - 1;
+        o.ext_image_words = (long long)o.ext_words * o.ext_rows;
+        o.vec_ok = (W % 4) == 0;
+        return best_cost;
+    };
+
+    MatchGeom g16, g8;
+    int rw16 = 0, rw8 = 0;
+    const double c16 = configure(16, g16, rw16);
+    bool use8 = false;
+    int l2;
+    if (bs && nl_for(8, l2) <= 32 && sm_bs_kernel_ptr(g.n, 8, true, ghost)) {
+        const double c8 = configure(8, g8, rw8);
+        (void)c8; (void)c16;
+        use8 = ds_env == 8;   // measured: 16 shifts/lane wins (fewer shared views and merge levels)
     }
-    if (th == 0) th = 1;
-    if (th_env > 0) th = std::min(th_env, H);
-    while (lds_of(th) > 64 * 1024 && th > 1) th--;
-    g.tile_h = th;
-    g.tiles_y = ceil_div(H, th);
-    g.nsr = th + g.n - 1;
-    g.lds_bytes = g.nsr * rows_words * 4;
-    g.ext_words = (g.tiles_x - 1) * (g.tw / 32) + g.prw + (bs ? 0 : 0);
-    g.ext_rows = g.tiles_y * th + g.n - 1;
-    g.ext_image_words = (long long)g.ext_words * g.ext_rows;
-    g.vec_ok = (W % 4) == 0;
+    g = use8 ? g8 : g16;
 
     snprintf(plan->describe, sizeof plan->describe,
              "%s (n=%d, D=%d, %s): tile %dx%d px, %d threads "
-             "(%d runs x %d shift-lanes), grid %dx%d, LDS %d B/wg, ext %dx%d words",
+             "(%d runs x %d shift-lanes of %d), grid %dx%d, LDS %d B/wg, ext %dx%d words",
              bs ? "bit-sliced kernel" : kernel == SM_KERNEL_A ? "tiled kernel A"
                 : kernel == SM_KERNEL_B ? "tiled kernel B" : "tiled kernel C",
-             g.n, D, plan->border == SM_GHOST ? "ghost" : "toroidal",
-             g.tw, g.tile_h, g.threads, g.runs, g.nl, g.tiles_x, g.tiles_y, g.lds_bytes,
+             g.n, D, ghost ? "ghost" : "toroidal",
+             g.tw, g.tile_h, g.threads, g.runs, g.nl, g.ds, g.tiles_x, g.tiles_y, g.lds_bytes,
              g.ext_words, g.ext_rows);
     return SM_OK;
 }

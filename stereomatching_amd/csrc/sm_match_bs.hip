@@ -32,6 +32,10 @@
 
 #include "sm_internal.h"
 
+#ifndef SM_BS_WAVES
+#define SM_BS_WAVES 1   // min waves per SIMD the register allocator must leave room for
+#endif
+
 template <int IMM>
 __device__ __forceinline__ u32 bop(u32 a, u32 b, u32 c)
 {
@@ -152,18 +156,17 @@ __device__ __forceinline__ u32 from_partner(u32 v)
 // the kernel
 // ---------------------------------------------------------------------------
 
-template <int N, bool FULLD, bool GHOST>
-__global__ __launch_bounds__(64) void k_match_bs(const u32 *__restrict__ ext,
+template <int N, int DS, bool FULLD, bool GHOST>
+__global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restrict__ ext,
                                                  i32 *__restrict__ web, i32 *__restrict__ best,
                                                  const MatchGeom g)
 {
-    constexpr int DS = SM_DSET;                 // 16 shifts per lane
     constexpr int HALF = N / 2;
     constexpr int HB = bits_for(N);             // planes of a horizontal count
     constexpr int SB = bits_for(N * N);         // planes of a window count; 2^SB - 1 > N*N
-    constexpr int AB = 4;                       // planes of the in-lane shift index
+    constexpr int AB = DS == 16 ? 4 : 3;        // planes of the in-lane shift index
     constexpr int ABMAX = AB + 6;               // after merging up to 64 lanes
-    constexpr int NV = N + DS - 1;              // shifted views of the right row
+    static_assert(SB <= 8, "window counts are moved through byte lanes");
     static_assert((1 << SB) - 1 > N * N, "the all-ones marker must not be a real count");
     static_assert(N + DS - 1 + 31 < 96, "right window must fit three words");
 
@@ -216,10 +219,10 @@ __global__ __launch_bounds__(64) void k_match_bs(const u32 *__restrict__ ext,
         for (int i = 0; i < N; i++) cvv[i] = i ? alignbit(c1, c0, i) : c0;
     }
     // shifts >= D of this lane never match
-    u32 dvalid = 0xffffu;
+    u32 dvalid = (1u << DS) - 1u;
     if (!FULLD) {
         const int dlim = g.D - d0;
-        dvalid = dlim >= DS ? 0xffffu : (dlim <= 0 ? 0u : ((1u << dlim) - 1u));
+        dvalid = dlim >= DS ? (1u << DS) - 1u : (dlim <= 0 ? 0u : ((1u << dlim) - 1u));
     }
 
     u32 S[DS][SB];
@@ -236,18 +239,25 @@ __global__ __launch_bounds__(64) void k_match_bs(const u32 *__restrict__ ext,
         u32 rw[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) rw[k] = alignbit(rr[k + 1], rr[k], shR);
-        u32 lv[N], rv[NV];
+        u32 lv[N];
 #pragma unroll
         for (int i = 0; i < N; i++) lv[i] = i ? alignbit(l1, l0, i) : l0;
+        // views of the right row: only the N that shift dd needs are alive
+        auto rview = [&](int j) -> u32 {
+            return (j & 31) ? alignbit(rw[(j >> 5) + 1], rw[j >> 5], j & 31) : rw[j >> 5];
+        };
+        u32 win[N];
 #pragma unroll
-        for (int j = 0; j < NV; j++)
-            rv[j] = (j & 31) ? alignbit(rw[(j >> 5) + 1], rw[j >> 5], j & 31) : rw[j >> 5];
+        for (int i = 0; i < N - 1; i++) win[i + 1] = rview(i);
 #pragma unroll
         for (int dd = 0; dd < DS; dd++) {
+#pragma unroll
+            for (int i = 0; i < N - 1; i++) win[i] = win[i + 1];
+            win[N - 1] = rview(dd + N - 1);
             u32 x[N], h[HB];
 #pragma unroll
             for (int i = 0; i < N; i++)
-                x[i] = GHOST ? bop<BOP_XOR_AND>(lv[i], rv[i + dd], cvv[i]) : (lv[i] ^ rv[i + dd]);
+                x[i] = GHOST ? bop<BOP_XOR_AND>(lv[i], win[i], cvv[i]) : (lv[i] ^ win[i]);
             count_bits<N, HB>(x, h);
             if (add) add_planes<SB, HB>(S[dd], h); else sub_planes<SB, HB>(S[dd], h);
         }
@@ -316,27 +326,29 @@ __global__ __launch_bounds__(64) void k_match_bs(const u32 *__restrict__ ext,
 #undef SM_MERGE
 
         // ---- planes -> integers.  After the merge all nl lanes of a word hold the
-        // same planes; lane s converts pixels [s*per, s*per + per), per = 32/nl.
+        // same planes; lane s converts pixels [s*per, s*per + per), per = 32/nl, in
+        // chunks of up to 4.  nib = the chunk's bits of a plane; nib * 0x204081 puts
+        // copy j of the nibble at bit 7j, so bit 8q holds pixel q's bit: & 0x01010101
+        // leaves one byte per pixel, and byte lanes then add up the planes.
         if (y < g.h) {
-            const int per = 32 >> g.log2nl;
-            const int p0 = s * per;
-            if (per == 4 && g.D <= 256 && SB <= 8) {
-                // 4 pixels at once.  nib = the 4 bits of a plane; nib * 0x204081 puts
-                // copy j of the nibble at bit 7j, so bit 8q holds pixel q's bit:
-                // & 0x01010101 leaves one byte per pixel; byte lanes then add up planes.
-                u32 ab = 0, bb = 0, allone = 0xffffffffu;
+            const int per = 32 >> g.log2nl;            // nl <= 32
+            const int cw = per < 4 ? per : 4;          // pixels per chunk
+            const u32 cmask = (1u << cw) - 1u;
+            u32 allone = B[0];
 #pragma unroll
-                for (int k = 0; k < SB; k++) {
-                    const u32 nib = (B[k] >> p0) & 15u;
-                    bb += (__umul24(nib, 0x204081u) & 0x01010101u) << k;
-                    allone &= B[k];
-                }
+            for (int k = 1; k < SB; k++) allone &= B[k];
+            for (int c = 0; c < per; c += 4) {
+                const int p0 = s * per + c;
+                u32 bb = 0, alo = 0, ahi = 0;
 #pragma unroll
-                for (int k = 0; k < AB + 4; k++) {       // D <= 256: at most 8 planes
-                    const u32 nib = (arg[k] >> p0) & 15u;
-                    ab += (__umul24(nib, 0x204081u) & 0x01010101u) << k;
+                for (int k = 0; k < SB; k++)
+                    bb += (__umul24((B[k] >> p0) & cmask, 0x204081u) & 0x01010101u) << k;
+#pragma unroll
+                for (int k = 0; k < ABMAX; k++) {
+                    const u32 sp = __umul24((arg[k] >> p0) & cmask, 0x204081u) & 0x01010101u;
+                    if (k < 8) alo += sp << k; else ahi += sp << (k - 8);
                 }
-                const u32 none = __umul24((allone >> p0) & 15u, 0x204081u) & 0x01010101u;   // 1 = no match
+                const u32 none = __umul24((allone >> p0) & cmask, 0x204081u) & 0x01010101u;
                 i32 wv[4], bv[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -348,42 +360,22 @@ __global__ __launch_bounds__(64) void k_match_bs(const u32 *__restrict__ ext,
                         const int rws = min(g.h - 1, y + HALF) - max(0, y - HALF) + 1;
                         taps = cols * rws;
                     }
-                    wv[q] = no ? g.D : (i32)((ab >> (8 * q)) & 255u) + 1;
+                    const i32 a = (i32)(((alo >> (8 * q)) & 255u) | (((ahi >> (8 * q)) & 255u) << 8));
+                    wv[q] = no ? g.D : a + 1;
                     bv[q] = no ? 0 : taps - (i32)((bb >> (8 * q)) & 255u);
                 }
                 const int x = x0 + p0;
                 const size_t o = ((size_t)pair * g.h + y) * g.w + x;
-                if (g.vec_ok && x + 4 <= g.w) {
+                if (cw == 4 && g.vec_ok && x + 4 <= g.w) {
                     *reinterpret_cast<int4 *>(web + o) = make_int4(wv[0], wv[1], wv[2], wv[3]);
                     if (best) *reinterpret_cast<int4 *>(best + o) = make_int4(bv[0], bv[1], bv[2], bv[3]);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; q++)
-                        if (x + q < g.w) {
+                        if (q < cw && x + q < g.w) {
                             web[o + q] = wv[q];
                             if (best) best[o + q] = bv[q];
                         }
-                }
-            } else {
-                for (int q = 0; q < per; q++) {
-                    const int p = p0 + q;
-                    const int x = x0 + p;
-                    if (x >= g.w) break;
-                    u32 bsum = 0, a = 0;
-#pragma unroll
-                    for (int k = 0; k < SB; k++) bsum |= ((B[k] >> p) & 1u) << k;
-#pragma unroll
-                    for (int k = 0; k < ABMAX; k++) a |= ((arg[k] >> p) & 1u) << k;
-                    const bool any = bsum != (1u << SB) - 1u;
-                    int taps = N * N;
-                    if (GHOST) {
-                        const int cols = min(g.w - 1, x + HALF) - max(0, x - HALF) + 1;
-                        const int rws = min(g.h - 1, y + HALF) - max(0, y - HALF) + 1;
-                        taps = cols * rws;
-                    }
-                    const size_t o = ((size_t)pair * g.h + y) * g.w + x;
-                    web[o] = any ? (i32)a + 1 : g.D;
-                    if (best) best[o] = any ? taps - (i32)bsum : 0;
                 }
             }
         }
@@ -394,29 +386,31 @@ __global__ __launch_bounds__(64) void k_match_bs(const u32 *__restrict__ ext,
 // host side
 // ---------------------------------------------------------------------------
 
-template <int N>
+template <int N, int DS>
 static const void *bs_ptr(bool fulld, bool ghost)
 {
-    return fulld ? (ghost ? (const void *)k_match_bs<N, true, true> : (const void *)k_match_bs<N, true, false>)
-                 : (ghost ? (const void *)k_match_bs<N, false, true> : (const void *)k_match_bs<N, false, false>);
+    return fulld ? (ghost ? (const void *)k_match_bs<N, DS, true, true> : (const void *)k_match_bs<N, DS, true, false>)
+                 : (ghost ? (const void *)k_match_bs<N, DS, false, true> : (const void *)k_match_bs<N, DS, false, false>);
 }
 
-const void *sm_bs_kernel_ptr(int n, bool fulld, bool ghost)
+const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost)
 {
+#define SM_BS_ROW(N) return ds == 16 ? bs_ptr<N, 16>(fulld, ghost) : ds == 8 ? bs_ptr<N, 8>(fulld, ghost) : nullptr
     switch (n) {
-    case 5: return bs_ptr<5>(fulld, ghost);
-    case 7: return bs_ptr<7>(fulld, ghost);
-    case 9: return bs_ptr<9>(fulld, ghost);
-    case 11: return bs_ptr<11>(fulld, ghost);
+    case 5: SM_BS_ROW(5);
+    case 7: SM_BS_ROW(7);
+    case 9: SM_BS_ROW(9);
+    case 11: SM_BS_ROW(11);
     default: return nullptr;
     }
+#undef SM_BS_ROW
 }
 
 int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
 {
     const MatchGeom &g = plan->g;
-    const void *fn = sm_bs_kernel_ptr(g.n, g.nl * SM_DSET == g.D, plan->border == SM_GHOST);
-    if (!fn) return sm_fail(SM_ERR_ARG, "bit-sliced kernel not built for n = %d", g.n);
+    const void *fn = sm_bs_kernel_ptr(g.n, g.ds, g.nl * g.ds == g.D, plan->border == SM_GHOST);
+    if (!fn) return sm_fail(SM_ERR_ARG, "bit-sliced kernel not built for n = %d, %d shifts/lane", g.n, g.ds);
     void *args[] = {(void *)&plan->d_ext, (void *)&d_web, (void *)&d_best, (void *)&g};
     hipError_t e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(g.threads), args,
                                    g.lds_bytes, st);

@@ -71,6 +71,20 @@ class StereoPlan:
     def workspace_bytes(self) -> int:
         return int(lib.sm_plan_workspace_bytes(self._h))
 
+    def set_pipelined(self, enabled: bool = True):
+        """Let consecutive run() calls overlap (edges of call i+1 beside the match of
+        call i).  The inputs given to run() must be complete in memory at call time."""
+        check(lib.sm_plan_set_pipelined(self._h, int(enabled)))
+
+    def time_kernels(self, capacity: int):
+        check(lib.sm_plan_time_kernels(self._h, int(capacity)))
+
+    def kernel_ms(self):
+        """(mean ms, launches) of the match launches recorded since time_kernels()."""
+        ms, n = C.c_double(0), C.c_int(0)
+        check(lib.sm_plan_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
 
