@@ -305,3 +305,72 @@ def test_baseline_config_full_size_properties(hip, cfg):
         assert np.array_equal(host(web2)[0], np.roll(web_h, (sy, sx), (0, 1)))
         assert np.array_equal(host(best2)[0], np.roll(best_h, (sy, sx), (0, 1)))
     plan.close()
+
+
+# ---------------------------------------------------------------------------
+# non-default code paths (selected by environment at plan creation)
+# ---------------------------------------------------------------------------
+
+@pytest.fixture
+def env(monkeypatch):
+    def setter(**kw):
+        for k, v in kw.items():
+            monkeypatch.setenv(k, str(v))
+    return setter
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("w,h,d,sw", [(300, 150, 128, 9), (71, 53, 30, 5), (130, 70, 64, 7), (90, 61, 64, 11)])
+@pytest.mark.parametrize("variant", [dict(SM_KERNEL="popcount"), dict(SM_DS=8), dict(SM_TILE_H=5),
+                                     dict(SM_DS=8, SM_TILE_H=7)])
+def test_alternative_kernels_match_oracle(hip, env, variant, mode, w, h, d, sw):
+    """the popcount kernels (general fallback), the 8-shifts-per-lane bit-sliced
+    variant and odd tile heights give the same bits as the default path"""
+    env(**variant)
+    le, re = rand_edges(w, h, seed=w + d)
+    best, web, desc = hip_hot_path(hip, le, re, d, sw, mode)
+    if "SM_KERNEL" in variant:
+        assert "tiled kernel" in desc
+    elif "SM_DS" in variant:
+        assert "lanes of 8" in desc
+    obest, oweb = oracle.hot_path(le, re, d, sw, mode)
+    assert np.array_equal(web[0], oweb), desc
+    assert np.array_equal(best[0], obest), desc
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+def test_one_pixel_edge_kernel(hip, env, mode):
+    env(SM_EDGES1=1)        # the kernel used when the width is not a multiple of 4
+    left, right = make_pair(128, 66, 16, seed=4)
+    plan = hip.StereoPlan(128, 66, 16, 5, mode)
+    el, er = plan.find_all_edges(dev(left), dev(right), 0.15)
+    assert np.array_equal(host(el)[0], oracle.find_all_edges(left, 0.15, mode))
+    assert np.array_equal(host(er)[0], oracle.find_all_edges(right, 0.15, mode))
+    plan.close()
+
+
+def test_pipelined_runs_and_kernel_timing(hip):
+    """sm_plan_set_pipelined: consecutive runs on alternating workspace halves give
+    the same maps as sequential runs; sm_plan_time_kernels counts the launches"""
+    w, h, d, sw = 320, 200, 64, 7
+    pairs = [make_pair(w, h, d, seed=40 + i) for i in range(5)]
+    plan = hip.StereoPlan(w, h, d, sw)
+    want = []
+    for l, r in pairs:
+        web, _ = plan.run(dev(l), dev(r), 0.15)
+        want.append(host(web)[0].copy())
+    plan.set_pipelined(True)
+    plan.time_kernels(len(pairs))
+    inputs = [(dev(l), dev(r)) for l, r in pairs]
+    torch.cuda.synchronize()
+    outs = [plan.run(a, b, 0.15)[0] for a, b in inputs]      # back to back, no sync in between
+    torch.cuda.synchronize()
+    for got, exp in zip(outs, want):
+        assert np.array_equal(host(got)[0], exp)
+    ms, n = plan.kernel_ms()
+    assert n == len(pairs) and ms > 0
+    # and the oracle agrees with the first one
+    o = oracle.pipeline(*pairs[0], 0.15, d, sw, step3=False)
+    assert np.array_equal(want[0], o["web-1"])
+    plan.time_kernels(0)
+    plan.close()
