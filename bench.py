@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--threshold", type=float, default=0.15)
     ap.add_argument("--with-best", action="store_true", help="also write score_best")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the CPU-baseline band")
+    ap.add_argument("--cpu-rows", type=int, default=192, help="rows of the CPU-baseline band")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the edge kernel of step i+1 with the match kernel of step i "
                          "(sm_plan_set_pipelined; measured: no net gain, both kernels are VALU-heavy)")
@@ -166,15 +166,19 @@ def main():
     amin_kernel = (4.0 * w * h * pairs + plan.workspace_bytes() / 2 / plan.max_pairs * pairs) \
         / (kernel_ms * 1e-3) / 1e9
     amin_step = A_MIN_BYTES * w * h * pairs / (elapsed / args.steps) / 1e9
-    traffic = None
+    # HBM bytes and VALU instruction count of one launch come from separate rocprofv3
+    # --pmc passes of this same command (tools/collect_profiles.sh), committed under
+    # profiles/; null if no profile exists for this configuration
+    traffic = valu_issue = None
     tfile = ROOT / "profiles" / "hbm_traffic.json"
     if tfile.exists():
         t = json.loads(tfile.read_text()).get(f"{args.config}:{pairs}")
-        traffic = t["bytes_per_launch"] if t else None
-    # integer-VALU view: ~6.3 lane-ops per pixel-disparity against
-    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
-    valu_peak = 256 * 4 * 32 * 2.4e9
-    valu_frac = 6.3 * units_per_step / (kernel_ms * 1e-3) / valu_peak
+        if t:
+            traffic = t["bytes_per_launch"]
+            if t.get("valu_wave_instructions_per_launch"):
+                # fraction of the chip's full-rate VALU issue (1024 SIMDs x one wave64
+                # instruction per ~1.0 ns) this launch sustained
+                valu_issue = t["valu_wave_instructions_per_launch"] / (kernel_ms * 1e-3) / (1024 * 1.0e9)
 
     out = {
         "metric": "Mpixel-disparities/s",
@@ -211,7 +215,7 @@ def main():
             "frac_min": round(amin_kernel / HBM_PEAK_GBPS, 5),
             "model_min": "compulsory bytes of this launch: packed edge bits in + i32 web out",
             "step_min_GBps": round(amin_step, 1),
-            "valu_frac_est": round(valu_frac, 3),
+            "valu_issue_frac": round(valu_issue, 3) if valu_issue else None,
         },
     }
     if gather_ms is not None:

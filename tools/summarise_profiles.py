@@ -37,12 +37,14 @@ summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in counters.
 traffic_file = dst.parent / "hbm_traffic.json"
 traffic = json.loads(traffic_file.read_text()) if traffic_file.exists() else {}
 for k, cs in summary.items():
-    if k.startswith("k_match_wta") and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+    if k.startswith("k_match") and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         traffic[key] = {
             "kernel": k,
             "fetch_size_kib_raw": cs["FETCH_SIZE"],
             "write_size_kib": cs["WRITE_SIZE"],
             "bytes_per_launch": int((2.0 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
+            "valu_wave_instructions_per_launch": cs.get("SQ_INSTS_VALU"),
+            "waves_per_launch": cs.get("SQ_WAVES"),
             "note": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE half-count "
                     "correction); L2->fabric requests, Infinity-Cache hits included",
             "source": str(dst),
