@@ -88,7 +88,12 @@ def main():
     from stereomatching_amd import shard
     from stereomatching_amd.synth import CONFIGS, make_pair
 
-    rank, local_rank, world = shard.init()
+    # rehearsal hooks for a 1-GPU box (never set by the driver): run N ranks on
+    # device 0 with the gloo backend to exercise the multi-process path
+    rehearsal = os.environ.get("SM_BENCH_REHEARSAL") == "1"
+    rank, local_rank, world = shard.init("gloo" if rehearsal else None)
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torchrun",
@@ -133,6 +138,9 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
+    # communicator start-up (RCCL) belongs to the warm-up, not to the timed region
+    shard.barrier()
+    shard.max_over_ranks(0.0, "cpu" if rehearsal else dev)
     # HIP events around the dominant kernel, recorded by the library on the stream
     # the kernel is launched on, over the timed region itself
     plan.time_kernels(args.steps)
@@ -143,7 +151,7 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     shard.barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, "cpu" if rehearsal else dev)
 
     kernel_ms, n_timed = plan.kernel_ms()
     assert n_timed == args.steps
@@ -155,9 +163,9 @@ def main():
         torch.cuda.synchronize(dev)
         shard.barrier()
         g0 = time.perf_counter()
-        shard.gather_maps(web, pairs * world, rank, world)
+        shard.gather_maps(web.cpu() if rehearsal else web, pairs * world, rank, world)
         torch.cuda.synchronize(dev)
-        gather_ms = shard.max_over_ranks(time.perf_counter() - g0, dev) * 1e3
+        gather_ms = shard.max_over_ranks(time.perf_counter() - g0, "cpu" if rehearsal else dev) * 1e3
 
     if rank != 0:
         return
