@@ -104,6 +104,7 @@ int sm_fail(int code, const char *fmt, ...);
 
 // sm_match_bs.hip (bit-sliced kernel; nullptr if not built for this window)
 const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost);
+int sm_bs_default_ds(int n);
 int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);
 
 // sm_match.hip

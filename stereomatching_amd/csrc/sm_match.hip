@@ -489,8 +489,8 @@ int sm_match_configure(sm_plan *plan)
         const char *force = getenv("SM_KERNEL");
         const bool want_bs = !(force && !strcmp(force, "popcount"));
         int l2;
-        if (want_bs && kernel != SM_KERNEL_GENERIC && nl_for(16, l2) <= 32 &&
-            sm_bs_kernel_ptr(g.n, 16, true, ghost))
+        const int ds0 = sm_bs_default_ds(g.n);
+        if (want_bs && kernel != SM_KERNEL_GENERIC && ds0 && nl_for(ds0, l2) <= 32)
             kernel = SM_KERNEL_BS;
     }
     plan->kernel = kernel;
@@ -593,17 +593,21 @@ int sm_match_configure(sm_plan *plan)
         return best_cost;
     };
 
-    MatchGeom g16, g8;
-    int rw16 = 0, rw8 = 0;
-    const double c16 = configure(16, g16, rw16);
-    bool use8 = false;
-    int l2;
-    if (bs && nl_for(8, l2) <= 32 && sm_bs_kernel_ptr(g.n, 8, true, ghost)) {
-        const double c8 = configure(8, g8, rw8);
-        (void)c8; (void)c16;
-        use8 = ds_env == 8;   // measured: 16 shifts/lane wins (fewer shared views and merge levels)
+    // shifts per lane: 16 for the popcount kernels; for the bit-sliced kernel what is
+    // built for this window (16 where it exists: measured faster than 8, fewer shared
+    // views and merge levels), SM_DS overrides for tuning
+    int ds = 16;
+    if (bs) {
+        ds = sm_bs_default_ds(g.n);
+        int l2;
+        if ((ds_env == 8 || ds_env == 16) && sm_bs_kernel_ptr(g.n, ds_env, true, ghost) &&
+            nl_for(ds_env, l2) <= 32)
+            ds = ds_env;
     }
-    g = use8 ? g8 : g16;
+    MatchGeom gsel;
+    int rws = 0;
+    configure(ds, gsel, rws);
+    g = gsel;
 
     snprintf(plan->describe, sizeof plan->describe,
              "%s (n=%d, D=%d, %s): tile %dx%d px, %d threads "

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     constexpr int SB = bits_for(N * N);         // planes of a window count; 2^SB - 1 > N*N
     constexpr int AB = DS == 16 ? 4 : 3;        // planes of the in-lane shift index
     constexpr int ABMAX = AB + 6;               // after merging up to 64 lanes
-    static_assert(SB <= 8, "window counts are moved through byte lanes");
+    static_assert(SB <= 16, "window counts are moved through two byte lanes");
     static_assert((1 << SB) - 1 > N * N, "the all-ones marker must not be a real count");
     static_assert(N + DS - 1 + 31 < 96, "right window must fit three words");
 
@@ -339,10 +339,12 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
             for (int k = 1; k < SB; k++) allone &= B[k];
             for (int c = 0; c < per; c += 4) {
                 const int p0 = s * per + c;
-                u32 bb = 0, alo = 0, ahi = 0;
+                u32 bb = 0, bhi = 0, alo = 0, ahi = 0;
 #pragma unroll
-                for (int k = 0; k < SB; k++)
-                    bb += (__umul24((B[k] >> p0) & cmask, 0x204081u) & 0x01010101u) << k;
+                for (int k = 0; k < SB; k++) {
+                    const u32 sp = __umul24((B[k] >> p0) & cmask, 0x204081u) & 0x01010101u;
+                    if (k < 8) bb += sp << k; else bhi += sp << (k - 8);
+                }
 #pragma unroll
                 for (int k = 0; k < ABMAX; k++) {
                     const u32 sp = __umul24((arg[k] >> p0) & cmask, 0x204081u) & 0x01010101u;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
                     }
                     const i32 a = (i32)(((alo >> (8 * q)) & 255u) | (((ahi >> (8 * q)) & 255u) << 8));
                     wv[q] = no ? g.D : a + 1;
-                    bv[q] = no ? 0 : taps - (i32)((bb >> (8 * q)) & 255u);
+                    bv[q] = no ? 0 : taps - (i32)(((bb >> (8 * q)) & 255u) | (((bhi >> (8 * q)) & 255u) << 8));
                 }
                 const int x = x0 + p0;
                 const size_t o = ((size_t)pair * g.h + y) * g.w + x;
@@ -393,17 +395,41 @@ static const void *bs_ptr(bool fulld, bool ghost)
                  : (ghost ? (const void *)k_match_bs<N, DS, false, true> : (const void *)k_match_bs<N, DS, false, false>);
 }
 
+// Built combinations.  16 shifts per lane up to 11 x 11 (the 16 x SB sum planes fit
+// two waves per SIMD); 8 per lane for the larger windows (9 planes per sum) and,
+// for 9 x 9, as a tuning alternative.
 const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost)
 {
-#define SM_BS_ROW(N) return ds == 16 ? bs_ptr<N, 16>(fulld, ghost) : ds == 8 ? bs_ptr<N, 8>(fulld, ghost) : nullptr
-    switch (n) {
-    case 5: SM_BS_ROW(5);
-    case 7: SM_BS_ROW(7);
-    case 9: SM_BS_ROW(9);
-    case 11: SM_BS_ROW(11);
-    default: return nullptr;
+    if (ds == 16) {
+        switch (n) {
+        case 3: return bs_ptr<3, 16>(fulld, ghost);
+        case 5: return bs_ptr<5, 16>(fulld, ghost);
+        case 7: return bs_ptr<7, 16>(fulld, ghost);
+        case 9: return bs_ptr<9, 16>(fulld, ghost);
+        case 11: return bs_ptr<11, 16>(fulld, ghost);
+        default: return nullptr;
+        }
     }
-#undef SM_BS_ROW
+    if (ds == 8) {
+        switch (n) {
+        case 9: return bs_ptr<9, 8>(fulld, ghost);
+        case 13: return bs_ptr<13, 8>(fulld, ghost);
+        case 15: return bs_ptr<15, 8>(fulld, ghost);
+        case 17: return bs_ptr<17, 8>(fulld, ghost);
+        case 19: return bs_ptr<19, 8>(fulld, ghost);
+        case 21: return bs_ptr<21, 8>(fulld, ghost);
+        default: return nullptr;
+        }
+    }
+    return nullptr;
+}
+
+// shifts per lane the plan should use for this window (0: not built)
+int sm_bs_default_ds(int n)
+{
+    if (sm_bs_kernel_ptr(n, 16, true, false)) return 16;
+    if (sm_bs_kernel_ptr(n, 8, true, false)) return 8;
+    return 0;
 }
 
 int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)

@@ -17,6 +17,8 @@ CONFIGS = {
     "C3": (3840, 2160, 128, 9, "toroidal"),
     "C4": (1920, 1080, 64, 7, "toroidal"),  # x64 pairs, sharded
     "C5": (3840, 2160, 256, 11, "ghost"),
+    # the reference's own defaults (NUM_SHIFTS 30, square_width 21) at its 4K test size
+    "REF4K": (3840, 2160, 30, 21, "toroidal"),
 }
 
 

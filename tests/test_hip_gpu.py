@@ -331,7 +331,7 @@ def test_alternative_kernels_match_oracle(hip, env, variant, mode, w, h, d, sw):
     best, web, desc = hip_hot_path(hip, le, re, d, sw, mode)
     if "SM_KERNEL" in variant:
         assert "tiled kernel" in desc
-    elif "SM_DS" in variant:
+    elif "SM_DS" in variant and sw in (8, 9):       # the 8-per-lane variant is built for 9x9
         assert "lanes of 8" in desc
     obest, oweb = oracle.hot_path(le, re, d, sw, mode)
     assert np.array_equal(web[0], oweb), desc
