@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
 // neighbours left and right, so a row costs 0.75 loads per pixel instead of 3.
 // A lane's 4 decisions form a nibble; 8 adjacent lanes OR their nibbles
 // together (DPP) into one ext word.
-#define SM_EDGE4_ROWS 16
+#define SM_EDGE4_ROWS 8
 template <bool GHOST, bool TABLES>
 __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l,
                                                     const u8 *__restrict__ src_r,
