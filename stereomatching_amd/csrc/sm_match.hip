@@ -1,5 +1,9 @@
-// sm_match.hip -- THE HOT PATH: match cost -> S x S window sum -> masked
-// score -> winner-take-all over the shifts, fused into one launch.
+// sm_match.hip -- the hot path (match cost -> S x S window sum -> masked
+// score -> winner-take-all over the shifts, one fused launch): plan geometry,
+// the general POPCOUNT kernels and the launch switch.  The common windows run
+// on the bit-sliced kernel of sm_match_bs.hip (about 2x faster); the kernels in
+// this file cover every other window up to 25 x 25 and D up to 1024, and the
+// generic kernel at the bottom everything beyond.
 //
 // Replaces, for all D shifts at once (paths relative to /root/reference):
 //   fillup_matches                src/stereo.cu:127-137   (src/stereo.c:113-127)
@@ -69,10 +73,6 @@ __device__ __forceinline__ u32 spread16(u32 x)
 __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh)
 {
     return __builtin_amdgcn_alignbit(hi, lo, sh);   // ((hi:lo) >> (sh & 31)) low 32
-}
-__device__ __forceinline__ u32 ubfe(u32 v, u32 off, u32 width)
-{
-    return __builtin_amdgcn_ubfe(v, off, width);
 }
 template <int CTRL>
 __device__ __forceinline__ i32 dpp_max(i32 v)
