@@ -61,6 +61,18 @@ int sm_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
 int sm_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
 int sm_stream_sync(int device, void *stream);
 
+/* pinned (page-locked) host buffers and asynchronous copies on a stream, for
+ * callers that feed pairs from host memory and want the transfers to overlap
+ * the kernels of neighbouring pairs (the reference copies synchronously from
+ * pageable memory, src/util.h:131-143).  sm_stream_create/destroy hand out
+ * plain hipStream_t handles for callers without a HIP runtime of their own.  */
+int sm_host_alloc(size_t bytes, void **h_ptr);
+int sm_host_free(void *h_ptr);
+int sm_memcpy_h2d_async(int device, void *d_dst, const void *h_src, size_t bytes, void *stream);
+int sm_memcpy_d2h_async(int device, void *h_dst, const void *d_src, size_t bytes, void *stream);
+int sm_stream_create(int device, void **stream);
+int sm_stream_destroy(int device, void *stream);
+
 /* ---- plan: geometry + private workspace for one image size ------------- *
  * num_shifts  = the reference's compile-time NUM_SHIFTS (src/stereo.c:6),
  *               here a run-time value, 1..65535

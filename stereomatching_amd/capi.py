@@ -43,6 +43,12 @@ _SIGNATURES = {
     "sm_memcpy_h2d": (_int, [_int, _vp, _vp, _sz]),
     "sm_memcpy_d2h": (_int, [_int, _vp, _vp, _sz]),
     "sm_stream_sync": (_int, [_int, _vp]),
+    "sm_host_alloc": (_int, [_sz, C.POINTER(_vp)]),
+    "sm_host_free": (_int, [_vp]),
+    "sm_memcpy_h2d_async": (_int, [_int, _vp, _vp, _sz, _vp]),
+    "sm_memcpy_d2h_async": (_int, [_int, _vp, _vp, _sz, _vp]),
+    "sm_stream_create": (_int, [_int, C.POINTER(_vp)]),
+    "sm_stream_destroy": (_int, [_int, _vp]),
     "sm_plan_create": (_int, [_int, _int, _int, _int, _int, _int, _int, C.POINTER(_vp)]),
     "sm_plan_destroy": (None, [_vp]),
     "sm_plan_describe": (C.c_char_p, [_vp]),

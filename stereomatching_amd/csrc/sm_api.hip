@@ -607,6 +607,51 @@ extern "C" int sm_stream_sync(int device, void *stream)
     return SM_OK;
 }
 
+extern "C" int sm_host_alloc(size_t bytes, void **h_ptr)
+{
+    if (!h_ptr) return sm_fail(SM_ERR_ARG, "sm_host_alloc: h_ptr is NULL");
+    *h_ptr = nullptr;
+    SM_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return SM_OK;
+}
+
+extern "C" int sm_host_free(void *h_ptr)
+{
+    SM_HIP(hipHostFree(h_ptr));
+    return SM_OK;
+}
+
+extern "C" int sm_memcpy_h2d_async(int device, void *d_dst, const void *h_src, size_t bytes, void *stream)
+{
+    SM_TRY(use_device(device));
+    SM_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return SM_OK;
+}
+
+extern "C" int sm_memcpy_d2h_async(int device, void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+    SM_TRY(use_device(device));
+    SM_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return SM_OK;
+}
+
+extern "C" int sm_stream_create(int device, void **stream)
+{
+    if (!stream) return sm_fail(SM_ERR_ARG, "sm_stream_create: stream is NULL");
+    SM_TRY(use_device(device));
+    hipStream_t st = nullptr;
+    SM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void *)st;
+    return SM_OK;
+}
+
+extern "C" int sm_stream_destroy(int device, void *stream)
+{
+    SM_TRY(use_device(device));
+    SM_HIP(hipStreamDestroy((hipStream_t)stream));
+    return SM_OK;
+}
+
 extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
                               int square_width, int border, int max_pairs, sm_plan **out)
 {

@@ -374,3 +374,37 @@ def test_pipelined_runs_and_kernel_timing(hip):
     assert np.array_equal(want[0], o["web-1"])
     plan.time_kernels(0)
     plan.close()
+
+
+def test_c_abi_alone_with_pinned_async_transfers(hip):
+    """the boundary without torch: device memory, pinned host memory, a stream and
+    async copies all come from the C ABI (what a C caller would do)"""
+    import ctypes as C
+    lib, check = hip.capi.lib, hip.capi.check
+    w, h, d, sw = 200, 120, 30, 7
+    left, right = make_pair(w, h, d, seed=8)
+    n = w * h
+    vp = C.c_void_p
+    hl, hr, hw_, dl, dr, dw, st, plan = (vp() for _ in range(8))
+    for p, nb in ((hl, n), (hr, n), (hw_, 4 * n)):
+        check(lib.sm_host_alloc(nb, C.byref(p)))
+    for p, nb in ((dl, n), (dr, n), (dw, 4 * n)):
+        check(lib.sm_malloc(0, nb, C.byref(p)))
+    C.memmove(hl, left.ctypes.data, n)
+    C.memmove(hr, right.ctypes.data, n)
+    check(lib.sm_stream_create(0, C.byref(st)))
+    check(lib.sm_plan_create(0, w, h, d, sw, 0, 1, C.byref(plan)))
+    check(lib.sm_memcpy_h2d_async(0, dl, hl, n, st))
+    check(lib.sm_memcpy_h2d_async(0, dr, hr, n, st))
+    check(lib.sm_run(plan, dl, dr, 0.15, 1, dw, None, st))
+    check(lib.sm_memcpy_d2h_async(0, hw_, dw, 4 * n, st))
+    check(lib.sm_stream_sync(0, st))
+    web = np.ctypeslib.as_array(C.cast(hw_, C.POINTER(C.c_int32)), (h, w)).copy()
+    want = oracle.pipeline(left, right, 0.15, d, sw, step3=False)["web-1"]
+    assert np.array_equal(web, want)
+    lib.sm_plan_destroy(plan)
+    check(lib.sm_stream_destroy(0, st))
+    for p in (dl, dr, dw):
+        check(lib.sm_free(0, p))
+    for p in (hl, hr, hw_):
+        check(lib.sm_host_free(p))
