@@ -33,7 +33,7 @@ endif
 
 HOST    := stereomatching_amd/host
 HIPLIB  := stereomatching_amd/libstereo_hip.so
-HIPSRC  := stereomatching_amd/csrc/sm_api.hip stereomatching_amd/csrc/sm_match.hip stereomatching_amd/csrc/sm_match_bs.hip
+HIPSRC  := stereomatching_amd/csrc/sm_api.hip stereomatching_amd/csrc/sm_match.hip stereomatching_amd/csrc/sm_match_bs.hip stereomatching_amd/csrc/sm_cost.hip
 HIPDEP  := $(HIPSRC) stereomatching_amd/csrc/sm_internal.h include/stereo_hip.h
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Iinclude -Istereomatching_amd/csrc
 # the programs find the library next to the package wherever the tree is copied

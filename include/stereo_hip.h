@@ -141,6 +141,20 @@ int sm_run(sm_plan *plan, const uint8_t *d_gray_left,
            const uint8_t *d_gray_right, double threshold, int pairs,
            int32_t *d_web, int32_t *d_best, void *stream);
 
+/* ---- SAD / SSD cost mode: PARITY UNPINNED ---------------------------------- *
+ * BASELINE.json words the hot path as "SAD/SSD cost, window aggregation,
+ * arg-min"; the reference implements the edge-equality cost above and nothing
+ * else, so this entry has NO reference counterpart.  Same skeleton on the uint8
+ * gray images themselves: c_d = |L(x,y) - R(x+d,y)| or its square, n x n box
+ * sum, best = min over d, web = 1 + the FIRST d reaching it; borders as the
+ * reference treats its edge images (wrap, or zeros past the border and no taps
+ * outside the image).  Defined by oracle/stereo_oracle.c smo_cost_hot_path.
+ * Windows up to 25 x 25, num_shifts <= 512.                                   */
+#define SM_COST_SAD 1
+#define SM_COST_SSD 2
+int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
+                int cost, int pairs, int32_t *d_web, int32_t *d_best, void *stream);
+
 /* debug tap: materialise the per-shift planes the reference dumps in debug
  * builds (matches-i, score_all-i, scores-i; src/stereo.c:98-104,:158-164,
  * :189) for one shift of one pair.  Any output may be NULL.  Slow path.    */

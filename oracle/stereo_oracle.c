@@ -253,6 +253,55 @@ void smo_hot_path(const uint8_t *le, const uint8_t *re, int w, int h,
 }
 
 /* ------------------------------------------------------------------ */
+/* SAD / SSD cost mode (no reference implementation: parity unpinned)  */
+/* ------------------------------------------------------------------ */
+
+void smo_cost_hot_path(const uint8_t *left, const uint8_t *right, int w, int h,
+                       int num_shifts, int square_width, int mode, int cost,
+                       int32_t *best, int32_t *web)
+{
+    const size_t n = (size_t)w * h;
+    const int half = square_width / 2;
+    i32 *c = zalloc(sizeof(i32) * n), *t = zalloc(sizeof(i32) * n);
+    for (size_t p = 0; p < n; p++) { best[p] = INT_MAX; web[p] = 0; }
+    for (int d = 0; d < num_shifts; d++) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int r;
+                if (mode == SMO_TOROIDAL) r = right[(size_t)y * w + wrap(x + d, w)];
+                else r = x + d < w ? right[(size_t)y * w + x + d] : 0;
+                int diff = (int)left[(size_t)y * w + x] - r;
+                c[(size_t)y * w + x] = cost == SMO_COST_SSD ? diff * diff : abs(diff);
+            }
+        for (int y = 0; y < h; y++)          /* horizontal pass */
+            for (int x = 0; x < w; x++) {
+                i32 s = 0;
+                for (int k = -half; k <= half; k++) {
+                    int xx = x + k;
+                    if (mode == SMO_TOROIDAL) s += c[(size_t)y * w + wrap(xx, w)];
+                    else if (xx >= 0 && xx < w) s += c[(size_t)y * w + xx];
+                }
+                t[(size_t)y * w + x] = s;
+            }
+        for (int y = 0; y < h; y++)          /* vertical pass + first-wins arg-min */
+            for (int x = 0; x < w; x++) {
+                i32 s = 0;
+                for (int k = -half; k <= half; k++) {
+                    int yy = y + k;
+                    if (mode == SMO_TOROIDAL) s += t[(size_t)wrap(yy, h) * w + x];
+                    else if (yy >= 0 && yy < h) s += t[(size_t)yy * w + x];
+                }
+                if (s < best[(size_t)y * w + x]) {
+                    best[(size_t)y * w + x] = s;
+                    web[(size_t)y * w + x] = d + 1;
+                }
+            }
+    }
+    free(c);
+    free(t);
+}
+
+/* ------------------------------------------------------------------ */
 /* step 3: hole filling and contour lines                              */
 /* ------------------------------------------------------------------ */
 

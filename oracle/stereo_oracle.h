@@ -67,6 +67,24 @@ void smo_hot_path(const uint8_t *left_edges, const uint8_t *right_edges,
                   int w, int h, int num_shifts, int square_width, int mode,
                   int faithful, int32_t *best, int32_t *web);
 
+/* ---- SAD / SSD cost mode: NOT in the reference ("parity unpinned") --------
+ * BASELINE.json words the hot path as "SAD/SSD per-pixel cost ... window
+ * aggregation ... winner-take-all argmin"; the reference implements the
+ * edge-equality cost above and nothing else.  This is the
+ * build's own definition of that mode, on the same skeleton, and the only
+ * thing the GPU's SAD mode is checked against:
+ *   c_d(x,y) = |L(x,y) - R(x+d,y)|          (SAD)   or its square (SSD), on the
+ *              uint8 gray images; R wraps (toroidal) or reads 0 past the right
+ *              border (ghost), like the edge images of the reference
+ *   A_d      = sum of c_d over the n x n window (wrapping, or taps outside the
+ *              image counting 0)
+ *   best     = min_d A_d ;  web = 1 + min{ d : A_d == best }   (first shift wins)
+ */
+enum { SMO_COST_SAD = 1, SMO_COST_SSD = 2 };
+void smo_cost_hot_path(const uint8_t *left, const uint8_t *right, int w, int h,
+                       int num_shifts, int square_width, int mode, int cost,
+                       int32_t *best, int32_t *web);
+
 /* step 3 */
 void smo_fill_web_holes(int32_t *web, int w, int h, int times);
 /* returns 0, or -1 when the reference would divide by zero */

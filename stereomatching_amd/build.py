@@ -17,7 +17,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libstereo_hip.so"
-SOURCES = ["sm_api.hip", "sm_match.hip", "sm_match_bs.hip"]
+SOURCES = ["sm_api.hip", "sm_match.hip", "sm_match_bs.hip", "sm_cost.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # the edge test must round exactly like the reference's C doubles

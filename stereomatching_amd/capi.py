@@ -60,6 +60,7 @@ _SIGNATURES = {
     "sm_plan_time_kernels": (_int, [_vp, _int]),
     "sm_plan_kernel_ms": (_int, [_vp, C.POINTER(C.c_double), _intp]),
     "sm_run": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp]),
+    "sm_cost_wta": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "sm_debug_planes": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp]),
     "sm_debug_edge_table": (_int, [_int, _dbl, _vp, _vp]),
     "sm_debug_edge_table_fast": (_int, [_vp, _dbl, _vp, _intp, _vp]),

@@ -144,6 +144,18 @@ class StereoPlan:
                          _ptr(best if want_best else None), self._stream()))
         return web, (best if want_best else None)
 
+    def cost_wta(self, left, right, cost="sad", want_best=True):
+        """SAD / SSD cost mode on the uint8 images (parity unpinned: the reference has no
+        such mode) -> (web, best): arg-min over the shifts, first shift wins."""
+        left = self._images(left, torch.uint8, "left")
+        right = self._images(right, torch.uint8, "right")
+        pairs = left.shape[0]
+        web = self._new(pairs, torch.int32)
+        best = self._new(pairs, torch.int32) if want_best else None
+        check(lib.sm_cost_wta(self._h, _ptr(left), _ptr(right), {"sad": 1, "ssd": 2}[cost], pairs,
+                              _ptr(web), _ptr(best), self._stream()))
+        return web, best
+
     def debug_planes(self, pair: int, shift: int):
         """matches-i, score_all-i, scores-i of the reference's debug build."""
         m = torch.empty((self.height, self.width), dtype=torch.uint8, device=self._dev)

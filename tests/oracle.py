@@ -47,6 +47,8 @@ def lib():
         L.smo_record_score.argtypes = [_u8p, _i32p, C.c_int, C.c_int, _i32p]
         L.smo_hot_path.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, _i32p, _i32p]
+        L.smo_cost_hot_path.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, _i32p, _i32p]
         L.smo_fill_web_holes.argtypes = [_i32p, C.c_int, C.c_int, C.c_int]
         L.smo_draw_contour_map.argtypes = [_i32p, C.c_int, C.c_int, C.c_int, _u8p]
         L.smo_draw_contour_map.restype = C.c_int
@@ -109,6 +111,21 @@ def hot_path(le, re, num_shifts, square_width, mode="toroidal", faithful=False):
     web = np.zeros((h, w), np.int32)
     lib().smo_hot_path(le, re, w, h, num_shifts, square_width, _mode(mode),
                        int(faithful), best, web)
+    return best, web
+
+
+COSTS = {"sad": 1, "ssd": 2}
+
+
+def cost_hot_path(left, right, num_shifts, square_width, mode="toroidal", cost="sad"):
+    """SAD/SSD mode (the build's own definition; no reference exists) -> (best, web)"""
+    left = np.ascontiguousarray(left, np.uint8)
+    right = np.ascontiguousarray(right, np.uint8)
+    h, w = left.shape
+    best = np.zeros((h, w), np.int32)
+    web = np.zeros((h, w), np.int32)
+    lib().smo_cost_hot_path(left, right, w, h, num_shifts, square_width, _mode(mode),
+                            COSTS[cost], best, web)
     return best, web
 
 

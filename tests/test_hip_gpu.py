@@ -408,3 +408,34 @@ def test_c_abi_alone_with_pinned_async_transfers(hip):
         check(lib.sm_free(0, p))
     for p in (hl, hr, hw_):
         check(lib.sm_host_free(p))
+
+
+# ---------------------------------------------------------------------------
+# SAD / SSD cost mode -- parity UNPINNED: the reference has no such mode; the only
+# oracle is the build's own C definition (oracle/stereo_oracle.c smo_cost_hot_path)
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("cost", ["sad", "ssd"])
+@pytest.mark.parametrize("w,h,d,sw", [(64, 40, 16, 5), (131, 67, 30, 9), (200, 50, 128, 9), (96, 70, 64, 7),
+                                      (80, 64, 40, 21), (57, 33, 8, 1), (300, 41, 256, 11), (40, 30, 100, 25)])
+def test_cost_mode_matches_own_oracle(hip, mode, cost, w, h, d, sw):
+    kind = "noise" if (w + h) % 2 else "scene"
+    left, right = make_pair(w, h, d, seed=w + sw, kind=kind)
+    plan = hip.StereoPlan(w, h, d, sw, mode)
+    web, best = plan.cost_wta(dev(left), dev(right), cost)
+    ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, cost)
+    assert np.array_equal(host(web)[0], ow), (cost, mode)
+    assert np.array_equal(host(best)[0], ob), (cost, mode)
+    plan.close()
+
+
+def test_cost_mode_recovers_a_known_shift(hip):
+    # right(x + 7) = left(x): SAD is zero exactly at shift 7 -> web = 8 away from flat regions
+    rng = np.random.default_rng(2)
+    left = rng.integers(0, 256, (60, 160), dtype=np.uint8)
+    right = np.roll(left, 7, 1)
+    plan = hip.StereoPlan(160, 60, 32, 5)
+    web, best = plan.cost_wta(dev(left), dev(right), "sad")
+    assert (host(web)[0] == 8).all() and (host(best)[0] == 0).all()
+    plan.close()
