@@ -37,7 +37,11 @@ def pairs_for_rank(total_pairs: int, rank: int, world: int) -> list[int]:
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            # name the device explicitly: one process per GPU, the current one
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(seconds: float, device="cpu") -> float:
