@@ -710,6 +710,20 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
         return sm_fail(e == hipErrorOutOfMemory ? SM_ERR_NOMEM : SM_ERR_HIP,
                        "sm_plan_create: workspace allocation failed: %s", hipGetErrorString(e));
     }
+    // Resolve the code objects of the kernels this plan will launch now (setup),
+    // so that the first timed launch does not pay the runtime's lazy loading.
+    {
+        hipFuncAttributes fa;
+        const bool gh = border == SM_GHOST;
+        const void *fns[] = {
+            (const void *)k_edge_thresholds, (const void *)k_pack_ext, (const void *)k_debug_planes,
+            (const void *)k_fill_holes_step, (const void *)k_count_zeros, (const void *)k_minmax_init,
+            (const void *)k_minmax, (const void *)k_contour,
+            gh ? (const void *)k_edges_ext4<true, true> : (const void *)k_edges_ext4<false, true>,
+            gh ? (const void *)k_edges_ext<true, true> : (const void *)k_edges_ext<false, true>,
+        };
+        for (const void *f : fns) (void)hipFuncGetAttributes(&fa, f);
+    }
     *out = p;
     return SM_OK;
 }
