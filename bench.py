@@ -105,6 +105,11 @@ def main():
 
     from stereomatching_amd import pipeline   # fails loudly if the HIP library is missing
 
+    # rank 0's job description goes to every rank (RCCL broadcast; a no-op at N = 1)
+    job = shard.broadcast_params(dict(config=args.config, pairs=args.pairs, threshold=args.threshold,
+                                      steps=args.steps, warmup=args.warmup))
+    args.config, args.pairs, args.threshold = job["config"], job["pairs"], job["threshold"]
+    args.steps, args.warmup = job["steps"], job["warmup"]
     w, h, d, sw, mode = CONFIGS[args.config]
     pairs = args.pairs
     plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs, device=local_rank)

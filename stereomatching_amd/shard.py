@@ -35,6 +35,17 @@ def pairs_for_rank(total_pairs: int, rank: int, world: int) -> list[int]:
     return list(range(rank, total_pairs, world))
 
 
+def broadcast_params(params: dict, src: int = 0) -> dict:
+    """Rank `src`'s parameter block (configuration, threshold, batch size ...) to every
+    rank, so that all shards run the same job: the 'broadcast' half of the north star's
+    'RCCL broadcast / gather only for result collection'.  A few hundred bytes."""
+    if not dist.is_initialized():
+        return params
+    box = [params]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def barrier():
     if dist.is_initialized():
         if dist.get_backend() == "nccl":

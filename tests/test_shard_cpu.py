@@ -44,6 +44,8 @@ def _worker(rank, world, port, total_pairs, out_dir):
     from tests import oracle
     r, lr, w = shard.init("gloo")
     assert (r, w) == (rank, world)
+    got = shard.broadcast_params({"config": "C3", "pairs": 3} if rank == 0 else {"config": "?"})
+    assert got == {"config": "C3", "pairs": 3}
     mine = shard.pairs_for_rank(total_pairs, rank, world)
     # every rank "processes" its own pairs with the CPU oracle standing in for the
     # device (this test is about the sharding / collection logic, not the kernels)
