@@ -439,3 +439,25 @@ def test_cost_mode_recovers_a_known_shift(hip):
     web, best = plan.cost_wta(dev(left), dev(right), "sad")
     assert (host(web)[0] == 8).all() and (host(best)[0] == 0).all()
     plan.close()
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+def test_batched_run_from_gray_images(hip, mode):
+    """sm_run on a batch: edge detection and matching of every pair of the batch in
+    single launches, partial batches of a larger plan included"""
+    w, h, d, sw, n = 132, 75, 30, 9, 4
+    pairs = [make_pair(w, h, d, seed=60 + i, kind="noise" if i == 2 else "scene") for i in range(n)]
+    left = np.stack([p[0] for p in pairs]); right = np.stack([p[1] for p in pairs])
+    plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=6)
+    web, best = plan.run(dev(left), dev(right), 0.2, want_best=True)
+    el, er = plan.find_all_edges(dev(left), dev(right), 0.2)
+    for i in range(n):
+        o = oracle.pipeline(pairs[i][0], pairs[i][1], 0.2, d, sw, mode=mode, step3=False)
+        assert np.array_equal(host(web)[i], o["web-1"]), i
+        assert np.array_equal(host(best)[i], o["score_best-0"]), i
+        assert np.array_equal(host(el)[i], o["edges-1"]) and np.array_equal(host(er)[i], o["edges-2"]), i
+    # a different threshold on the same plan rebuilds the decision tables
+    web2, _ = plan.run(dev(left[:1]), dev(right[:1]), 0.05)
+    assert np.array_equal(host(web2)[0], oracle.pipeline(pairs[0][0], pairs[0][1], 0.05, d, sw, mode=mode,
+                                                          step3=False)["web-1"])
+    plan.close()
