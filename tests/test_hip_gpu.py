@@ -461,3 +461,27 @@ def test_batched_run_from_gray_images(hip, mode):
     assert np.array_equal(host(web2)[0], oracle.pipeline(pairs[0][0], pairs[0][1], 0.05, d, sw, mode=mode,
                                                           step3=False)["web-1"])
     plan.close()
+
+
+def _random_geometries(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        w = int(rng.integers(1, 330)); h = int(rng.integers(1, 200))
+        sw = int(rng.integers(0, min(26, w, h) + 1))
+        d = int(rng.choice([1, 2, 7, 16, 17, 30, 33, 64, 100, 128, 200, 255, 300]))
+        mode = "ghost" if rng.integers(0, 2) else "toroidal"
+        dens = float(rng.choice([0.05, 0.3, 0.5, 0.9]))
+        out.append((w, h, d, sw, mode, dens))
+    return out
+
+
+@pytest.mark.parametrize("w,h,d,sw,mode,dens", _random_geometries(70, seed=2026))
+def test_hot_path_random_geometries(hip, w, h, d, sw, mode, dens):
+    """seeded sweep over the geometry space: every size class, shift count, window and
+    border the plan logic can be given (all four kernel families are hit)"""
+    le, re = rand_edges(w, h, seed=w * 1000 + h, density=dens)
+    best, web, desc = hip_hot_path(hip, le, re, d, sw, mode)
+    obest, oweb = oracle.hot_path(le, re, d, sw, mode)
+    assert np.array_equal(web[0], oweb), desc
+    assert np.array_equal(best[0], obest), desc
