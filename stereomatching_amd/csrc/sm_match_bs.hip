@@ -134,6 +134,31 @@ __device__ __forceinline__ void sub_planes(u32 (&s)[SB], const u32 (&h)[HB])
     }
 }
 
+// s += hn - ho in one pass: the HB-plane difference in two's complement (its sign is
+// the borrow out), then one ripple add of the sign-extended difference
+template <int SB, int HB>
+__device__ __forceinline__ void addsub_planes(u32 (&s)[SB], const u32 (&hn)[HB], const u32 (&ho)[HB])
+{
+    u32 dl[HB];
+    u32 b = ~hn[0] & ho[0];
+    dl[0] = hn[0] ^ ho[0];
+#pragma unroll
+    for (int k = 1; k < HB; k++) {
+        dl[k] = bop<BOP_XOR3>(hn[k], ho[k], b);
+        b = bop<BOP_BORROW>(hn[k], ho[k], b);
+    }
+    const u32 sg = b;                       // all higher planes of the difference
+    u32 c = s[0] & dl[0];
+    s[0] ^= dl[0];
+#pragma unroll
+    for (int k = 1; k < SB; k++) {
+        const u32 a = k < HB ? dl[k] : sg;
+        const u32 t = bop<BOP_XOR3>(s[k], a, c);
+        if (k + 1 < SB) c = bop<BOP_MAJ>(s[k], a, c);
+        s[k] = t;
+    }
+}
+
 template <int CTRL>
 __device__ __forceinline__ u32 dpp(u32 v)
 {
@@ -231,35 +256,65 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
 #pragma unroll
         for (int k = 0; k < SB; k++) S[dd][k] = 0;
 
-    // one window row into (add) or out of (sub) all 16 sums
-    auto slide = [&](int srow, bool add) {
+    // the views one window row contributes: N pre-shifted words of the left row and
+    // the three words the right row's sliding views are cut from
+    struct RowViews { u32 lv[N]; u32 rw[3]; };
+    auto load_views = [&](int srow, RowViews &v) {
         const u32 *rl = pL + srow * plw + wL;
         const u32 *rr = pR + srow * prw + wR;
         const u32 l0 = alignbit(rl[1], rl[0], shL), l1 = alignbit(rl[2], rl[1], shL);
-        u32 rw[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) rw[k] = alignbit(rr[k + 1], rr[k], shR);
-        u32 lv[N];
+        for (int k = 0; k < 3; k++) v.rw[k] = alignbit(rr[k + 1], rr[k], shR);
 #pragma unroll
-        for (int i = 0; i < N; i++) lv[i] = i ? alignbit(l1, l0, i) : l0;
-        // views of the right row: only the N that shift dd needs are alive
-        auto rview = [&](int j) -> u32 {
-            return (j & 31) ? alignbit(rw[(j >> 5) + 1], rw[j >> 5], j & 31) : rw[j >> 5];
-        };
+        for (int i = 0; i < N; i++) v.lv[i] = i ? alignbit(l1, l0, i) : l0;
+    };
+    auto rview = [&](const RowViews &v, int j) -> u32 {
+        return (j & 31) ? alignbit(v.rw[(j >> 5) + 1], v.rw[j >> 5], j & 31) : v.rw[j >> 5];
+    };
+    // mismatch count of shift dd in one row (win = the N right views of this shift)
+    auto count_row = [&](const RowViews &v, const u32 (&win)[N], u32 (&h)[HB]) {
+        u32 x[N];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            x[i] = GHOST ? bop<BOP_XOR_AND>(v.lv[i], win[i], cvv[i]) : (v.lv[i] ^ win[i]);
+        count_bits<N, HB>(x, h);
+    };
+
+    // one window row into (add) or out of (sub) all sums
+    auto slide = [&](int srow, bool add) {
+        RowViews v;
+        load_views(srow, v);
         u32 win[N];
 #pragma unroll
-        for (int i = 0; i < N - 1; i++) win[i + 1] = rview(i);
+        for (int i = 0; i < N - 1; i++) win[i + 1] = rview(v, i);
 #pragma unroll
         for (int dd = 0; dd < DS; dd++) {
 #pragma unroll
             for (int i = 0; i < N - 1; i++) win[i] = win[i + 1];
-            win[N - 1] = rview(dd + N - 1);
-            u32 x[N], h[HB];
-#pragma unroll
-            for (int i = 0; i < N; i++)
-                x[i] = GHOST ? bop<BOP_XOR_AND>(lv[i], win[i], cvv[i]) : (lv[i] ^ win[i]);
-            count_bits<N, HB>(x, h);
+            win[N - 1] = rview(v, dd + N - 1);
+            u32 h[HB];
+            count_row(v, win, h);
             if (add) add_planes<SB, HB>(S[dd], h); else sub_planes<SB, HB>(S[dd], h);
+        }
+    };
+    // steady state: one row in and one row out, applied as a single signed difference
+    auto slide_both = [&](int srow_new, int srow_old) {
+        RowViews vn, vo;
+        load_views(srow_new, vn);
+        load_views(srow_old, vo);
+        u32 wn[N], wo[N];
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) { wn[i + 1] = rview(vn, i); wo[i + 1] = rview(vo, i); }
+#pragma unroll
+        for (int dd = 0; dd < DS; dd++) {
+#pragma unroll
+            for (int i = 0; i < N - 1; i++) { wn[i] = wn[i + 1]; wo[i] = wo[i + 1]; }
+            wn[N - 1] = rview(vn, dd + N - 1);
+            wo[N - 1] = rview(vo, dd + N - 1);
+            u32 hn[HB], ho[HB];
+            count_row(vn, wn, hn);
+            count_row(vo, wo, ho);
+            addsub_planes<SB, HB>(S[dd], hn, ho);
         }
     };
 
@@ -269,12 +324,12 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
         // staged row e is image row ty0 - HALF + e; ghost rows outside the image
         // hold no valid tap: nothing to add or remove
         {
-            const int y_new = ty0 - HALF + e;
-            if (!GHOST || (y_new >= 0 && y_new < g.h)) slide(e, true);
-            if (e >= N) {
-                const int y_old = y_new - N;
-                if (!GHOST || (y_old >= 0 && y_old < g.h)) slide(e - N, false);
-            }
+            const int y_new = ty0 - HALF + e, y_old = y_new - N;
+            const bool has_new = !GHOST || (y_new >= 0 && y_new < g.h);
+            const bool has_old = e >= N && (!GHOST || (y_old >= 0 && y_old < g.h));
+            if (has_new && has_old) slide_both(e, e - N);
+            else if (has_new) slide(e, true);
+            else if (has_old) slide(e - N, false);
         }
         if (e < N - 1) continue;
 
