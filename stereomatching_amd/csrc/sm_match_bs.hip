@@ -33,7 +33,7 @@
 #include "sm_internal.h"
 
 #ifndef SM_BS_WAVES
-#define SM_BS_WAVES 1   // min waves per SIMD the register allocator must leave room for
+#define SM_BS_WAVES 2   // min waves per SIMD: keeps VGPR + AGPR <= 256 (one AGPR more halves the occupancy)
 #endif
 
 template <int IMM>
