@@ -139,9 +139,10 @@ __global__ __launch_bounds__(256) void k_edge_thresholds(double threshold, u32 *
 #define SM_EDGE_MARGIN 1024
 __device__ __forceinline__ int edge_delta(int sa, int sb, int t_fix)
 {
-    const int d = sa - sb;
-    // sums < 2^11 and t_fix <= 2^19: the 24-bit multiply is exact
-    return ((d < 0 ? -d : d) << SM_EDGE_FIX) - (int)__umul24((u32)(sa + sb), (u32)t_fix);
+    // |sa - sb| in one v_sad_u32; sums < 2^11 and t_fix <= 2^19: the 24-bit multiply is exact
+    u32 ad;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(ad) : "v"(sa), "v"(sb));
+    return (int)(ad << SM_EDGE_FIX) - (int)__umul24((u32)(sa + sb), (u32)t_fix);
 }
 __device__ __forceinline__ bool edge_from_table(const u32 *tab, int sa, int sb)
 {

@@ -59,11 +59,17 @@ for r in range(rounds + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            assert lib.sm_match_wta(plan, pairs, web.data_ptr(), None, None) == 0
+            if os.environ.get("AB_EDGES"):
+                assert lib.sm_find_edges(plan, L.data_ptr(), R.data_ptr(), 0.15, pairs, None, None, None) == 0
+            else:
+                assert lib.sm_match_wta(plan, pairs, web.data_ptr(), None, None) == 0
         e1.record()
         torch.cuda.synchronize()
         if r:
             times[name].append(e0.elapsed_time(e1) / 5 * 1e3)
+        if os.environ.get("AB_EDGES"):
+            assert lib.sm_match_wta(plan, pairs, web.data_ptr(), None, None) == 0
+            torch.cuda.synchronize()
         if ref is None:
             ref = web.clone()
         else:
