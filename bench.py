@@ -43,8 +43,8 @@ A_MIN_BYTES = 6.0               # per pixel          
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3", help="BASELINE.json configuration C1..C5")
     ap.add_argument("--pairs", type=int, default=1, help="stereo pairs per GPU per step")
     ap.add_argument("--threshold", type=float, default=0.15)

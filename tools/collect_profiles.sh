@@ -18,5 +18,5 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   n=$(echo $set | cut -d" " -f1)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/pmc_$n" -- python3 bench.py $ARGS > "$OUT/pmc_$n.log" 2>&1 || echo "pmc pass $n failed"
 done
-python3 bench.py --steps 50 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err" || echo "bench failed"
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || echo "bench failed"
 ls "$OUT"
