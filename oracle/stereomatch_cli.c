@@ -65,27 +65,19 @@ int main(int argc, char *argv[])
     }
     uint8_t *left = NULL, *right = NULL;
     int w, h, w2, h2;
-    if (read_image_u8(argv[1], &left, &w, &h)) return 1;
-    if (read_image_u8(argv[2], &right, &w2, &h2)) return 1;
+    if (read_image_u8(argv[1], &left, &w, &h) || read_image_u8(argv[2], &right, &w2, &h2))
+        return 1;
     if (w != w2 || h != h2) {
         fprintf(stderr, "error: the two images must have equal width and height\n");
         return 1;
     }
-    if (argc >= 4 && parse_double(argv[3], &threshold)) {
-        fprintf(stderr, "error: threshold must be a number\n");
-        return 1;
-    }
-    if (argc >= 5 && parse_int(argv[4], &square_width)) {
-        fprintf(stderr, "error: square_width must be a number\n");
-        return 1;
-    }
-    if (argc >= 6 && parse_int(argv[5], &times)) {
-        fprintf(stderr, "error: times must be a number\n");
-        return 1;
-    }
-    if (argc >= 7 && parse_int(argv[6], &lines)) {
-        fprintf(stderr, "error: lines must be a number\n");
-        return 1;
+    static const char *const NAMES[] = {"threshold", "square_width", "times", "lines"};
+    int *ints[] = {NULL, &square_width, &times, &lines};
+    for (int i = 0; i < 4 && 3 + i < argc; i++) {
+        if (i == 0 ? parse_double(argv[3], &threshold) : parse_int(argv[3 + i], ints[i])) {
+            fprintf(stderr, "error: %s must be a number\n", NAMES[i]);
+            return 1;
+        }
     }
     if (threshold < 0.0 || threshold > 1.0) {
         fprintf(stderr, "error: threshold must be between 0 and 1\n");

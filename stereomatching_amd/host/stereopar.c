@@ -157,51 +157,51 @@ static void algorithm(const uint8_t *first, const uint8_t *second, int width, in
     sm_plan_destroy(plan);
 }
 
+/* optional positional arguments after the two images, in order */
+enum { ARG_DOUBLE, ARG_INT };
+static const struct {
+    const char *name;   /* as it appears in "error: <name> must be a number" */
+    int kind;
+} OPTIONAL_ARGS[] = {{"threshold", ARG_DOUBLE}, {"square_width", ARG_INT}, {"times", ARG_INT}, {"lines", ARG_INT}};
+
+static int fail(const char *message)
+{
+    fprintf(stderr, "%s\n", message);
+    return 1;
+}
+
 int main(int argc, char *argv[])
 {
+    AlgorithmParams params = {DEFAULT_THRESHOLD, DEFAULT_SQUARE_WIDTH, DEFAULT_TIMES, DEFAULT_LINES};
     if (argc < 3) {
         fprintf(stderr, "usage: stereomatch [image 1] [image 2] [threshold = %g] "
                         "[square_width = %d] [times = %d] [lines = %d]\n",
-                DEFAULT_THRESHOLD, DEFAULT_SQUARE_WIDTH, DEFAULT_TIMES, DEFAULT_LINES);
+                params.threshold, params.square_width, params.times, params.lines_to_draw);
         return 1;
     }
 
-    uint8_t *first = NULL, *second = NULL;
-    int w1, h1, w2, h2;
-    if (read_image_u8(argv[1], &first, &w1, &h1))
-        return 1;
-    if (read_image_u8(argv[2], &second, &w2, &h2))
-        return 1;
-    if (w1 != w2 || h1 != h2) {
-        fprintf(stderr, "error: the two images must have equal width and height\n");
-        return 1;
-    }
+    uint8_t *host_image[2] = {NULL, NULL};
+    int width[2], height[2];
+    for (int i = 0; i < 2; i++)
+        if (read_image_u8(argv[1 + i], &host_image[i], &width[i], &height[i]))
+            return 1;
+    if (width[0] != width[1] || height[0] != height[1])
+        return fail("error: the two images must have equal width and height");
 
-    AlgorithmParams params = {DEFAULT_THRESHOLD, DEFAULT_SQUARE_WIDTH, DEFAULT_TIMES, DEFAULT_LINES};
-    if (argc >= 4 && parse_double(argv[3], &params.threshold)) {
-        fprintf(stderr, "error: threshold must be a number\n");
-        return 1;
+    /* same order, parse rule and messages as the reference (src/stereo.cu:371-395) */
+    int *int_slot[] = {NULL, &params.square_width, &params.times, &params.lines_to_draw};
+    for (int i = 0; i < 4 && 3 + i < argc; i++) {
+        const int bad = OPTIONAL_ARGS[i].kind == ARG_DOUBLE ? parse_double(argv[3 + i], &params.threshold)
+                                                            : parse_int(argv[3 + i], int_slot[i]);
+        if (bad) {
+            fprintf(stderr, "error: %s must be a number\n", OPTIONAL_ARGS[i].name);
+            return 1;
+        }
     }
-    if (argc >= 5 && parse_int(argv[4], &params.square_width)) {
-        fprintf(stderr, "error: square_width must be a number\n");
-        return 1;
-    }
-    if (argc >= 6 && parse_int(argv[5], &params.times)) {
-        fprintf(stderr, "error: times must be a number\n");
-        return 1;
-    }
-    if (argc >= 7 && parse_int(argv[6], &params.lines_to_draw)) {
-        fprintf(stderr, "error: lines must be a number\n");
-        return 1;
-    }
-    if (params.threshold < 0.0 || params.threshold > 1.0) {
-        fprintf(stderr, "error: threshold must be between 0 and 1\n");
-        return 1;
-    }
-    if (params.square_width > w1 || params.square_width > h1) {
-        fprintf(stderr, "error: square width must not be higher than image width/height\n");
-        return 1;
-    }
+    if (params.threshold < 0.0 || params.threshold > 1.0)
+        return fail("error: threshold must be between 0 and 1");
+    if (params.square_width > width[0] || params.square_width > height[0])
+        return fail("error: square width must not be higher than image width/height");
 
     int num_shifts = NUM_SHIFTS;
     const char *env = getenv("STEREO_NUM_SHIFTS");
@@ -209,16 +209,18 @@ int main(int argc, char *argv[])
         num_shifts = atoi(env);
 
     /* upload (outside the timed region, like MAKE_GPU_COPY in src/stereo.cu:402-403) */
-    const size_t n = (size_t)w1 * h1;
-    uint8_t *first_gpu = gpu_alloc(n), *second_gpu = gpu_alloc(n);
-    GPU(sm_memcpy_h2d(0, first_gpu, first, n));
-    GPU(sm_memcpy_h2d(0, second_gpu, second, n));
+    const size_t n = (size_t)width[0] * height[0];
+    uint8_t *device_image[2];
+    for (int i = 0; i < 2; i++) {
+        device_image[i] = gpu_alloc(n);
+        GPU(sm_memcpy_h2d(0, device_image[i], host_image[i], n));
+    }
 
-    algorithm(first_gpu, second_gpu, w1, h1, params, num_shifts);
+    algorithm(device_image[0], device_image[1], width[0], height[0], params, num_shifts);
 
-    GPU(sm_free(0, first_gpu));
-    GPU(sm_free(0, second_gpu));
-    free(first);
-    free(second);
+    for (int i = 0; i < 2; i++) {
+        GPU(sm_free(0, device_image[i]));
+        free(host_image[i]);
+    }
     return 0;
 }
