@@ -13,6 +13,11 @@ GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # a fresh checkout has no binaries (they are git-ignored): build the HIP library
+    # in-tree before any test imports it.  hipcc cross-compiles without a GPU.
+    from stereomatching_amd import build
+    if not build.LIB.exists():
+        build.build_hip(verbose=True)
 
 
 def golden_cases():
