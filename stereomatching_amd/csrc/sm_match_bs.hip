@@ -13,7 +13,7 @@
 // at a time):
 //   x_i   = L(x+i) ^ R(x+i+d)                      mismatch bit of window column i
 //   Hx    = sum_i x_i        carry-save adder tree  (N inputs -> HB planes)
-//   Sx   += Hx(new row) ; Sx -= Hx(old row)         ripple add / subtract on SB planes
+//   Sx   += Hx(new row) - Hx(old row)               signed difference, one ripple add on SB planes
 //   upd   = centre_match & (Sx <= B)                borrow chain of B - Sx
 //   B     = upd ? Sx : B ;  arg = upd ? d : arg     v_bitop3 selects
 // Scores are kept as MISMATCH counts: the reference's score is
