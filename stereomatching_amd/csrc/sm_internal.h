@@ -84,6 +84,25 @@ struct sm_plan {
     char describe[512];
 };
 
+// XCD-aware tile order (device side).  Workgroups are dealt round-robin to the 8
+// XCDs by their linear id, so ids b and b+8 share an L2.  Mapping linear id ->
+// tile so that every XCD owns ONE contiguous run of tiles (row-major: a band of
+// image rows) lets the halo rows neighbouring tiles share, and the rows of the
+// packed image themselves, be fetched into one L2 instead of eight.  Bijective for
+// any tile count (MI355X guide, T1); placement is a speed matter only.
+#ifdef __HIPCC__
+__device__ __forceinline__ void sm_xcd_tile(int tiles_x, int tiles_y, int &tx, int &ty)
+{
+    const int n = tiles_x * tiles_y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, j = lin >> 3;
+    const int q = n >> 3, r = n & 7;                  // r XCDs get q + 1 tiles
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    ty = t / tiles_x;
+    tx = t - ty * tiles_x;
+}
+#endif
+
 // error plumbing (sm_api.hip)
 int sm_fail(int code, const char *fmt, ...);
 #define SM_HIP(call)                                                          \

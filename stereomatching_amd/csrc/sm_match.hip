@@ -169,8 +169,10 @@ __global__ __launch_bounds__(256) void k_match_wta(const u32 *__restrict__ ext,
 
     const int tid = threadIdx.x;
     const int pair = blockIdx.z;
-    const int tx0 = blockIdx.x * g.tw;
-    const int ty0 = blockIdx.y * g.tile_h;
+    int tile_x, tile_y;
+    sm_xcd_tile(g.tiles_x, g.tiles_y, tile_x, tile_y);
+    const int tx0 = tile_x * g.tw;
+    const int ty0 = tile_y * g.tile_h;
     const int n = g.n, half = g.half;
     const int plw = g.plw, prw = g.prw, nsr = g.nsr;
 

@@ -198,8 +198,10 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int tid = threadIdx.x;
     const int pair = blockIdx.z;
-    const int tx0 = blockIdx.x * g.tw;
-    const int ty0 = blockIdx.y * g.tile_h;
+    int tile_x, tile_y;
+    sm_xcd_tile(g.tiles_x, g.tiles_y, tile_x, tile_y);
+    const int tx0 = tile_x * g.tw;
+    const int ty0 = tile_y * g.tile_h;
     const int plw = g.plw, prw = g.prw, nsr = g.nsr;
     const u32 *extL = ext + (size_t)pair * 2 * g.ext_image_words;
     const u32 *extR = extL + g.ext_image_words;
