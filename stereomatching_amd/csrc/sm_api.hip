@@ -125,24 +125,23 @@ __global__ __launch_bounds__(256) void k_edge_thresholds(double threshold, u32 *
     }
 }
 
-// Integer prefilter in front of the tables.  In exact arithmetic the test is
-// |sa - sb| > threshold * (sa + sb) / 2 (the clamp to [0,1] never binds for
-// in-image sums).  With T = round(threshold/2 * 2^20),
-//     delta = |sa - sb| * 2^20 - (sa + sb) * T
-// differs from 2^20 * (|sa-sb| - threshold*(sa+sb)/2) by at most 0.5 * 1530 = 765,
-// so |delta| > 1024 leaves a real margin of > 2.4e-4 sum units, i.e. a relative
-// margin > 1e-7 on quantities the double evaluation gets right to ~1e-15: the
-// sign of delta IS the double decision.  Only |delta| <= 1024 (the few sum pairs
-// next to the boundary) consults the table.  Same function in the edge kernel
-// and in the exhaustive debug table, so the test covers what runs.
-#define SM_EDGE_FIX 20
-#define SM_EDGE_MARGIN 1024
-__device__ __forceinline__ int edge_delta(int sa, int sb, int t_fix)
+// f32 prefilter in front of the tables.  In exact arithmetic the test is
+//     E = |sa - sb| - theta * (sa + sb) > 0,   theta = threshold / 2
+// (the clamp to [0,1] never binds for in-image sums).  The sums are integers
+// below 2^11, exact in f32; with T = (float)theta,
+//     F = fma(sa + sb, -T, |sa - sb|)                        (one rounding)
+// differs from E by at most 1530 * |T - theta| <= 1530 * 2^-26 < 2.3e-5 plus the
+// fma rounding, which is <= 2^-25 whenever |F| < 1.  So |F| > 2^-12 (2.4e-4)
+// leaves a real margin > 2e-4 sum units -- a relative margin > 1e-7 on
+// quantities the double evaluation gets right to ~1e-15: the sign of F IS the
+// double decision.  Only |F| <= 2^-12 (the few sum pairs next to the boundary)
+// consults the table.  Same function in the edge kernels and in the exhaustive
+// debug table, so the test covers what runs.  Three full-rate VALU operations
+// per orientation (the abs and the negation are source modifiers).
+#define SM_EDGE_MARGIN 0.000244140625f
+__device__ __forceinline__ float edge_delta(float sa, float sb, float neg_t)
 {
-    // |sa - sb| in one v_sad_u32; sums < 2^11 and t_fix <= 2^19: the 24-bit multiply is exact
-    u32 ad;
-    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(ad) : "v"(sa), "v"(sb));
-    return (int)(ad << SM_EDGE_FIX) - (int)__umul24((u32)(sa + sb), (u32)t_fix);
+    return __builtin_fmaf(sa + sb, neg_t, __builtin_fabsf(sa - sb));
 }
 __device__ __forceinline__ bool edge_from_table(const u32 *tab, int sa, int sb)
 {
@@ -150,28 +149,71 @@ __device__ __forceinline__ bool edge_from_table(const u32 *tab, int sa, int sb)
     return sb <= (int)(short)(lh & 0xffff) || sb >= (int)(lh >> 16);
 }
 
-__global__ void k_edge_table_fast(const u32 *__restrict__ tab, int t_fix, u8 *__restrict__ table)
+__global__ void k_edge_table_fast(const u32 *__restrict__ tab, float neg_t, u8 *__restrict__ table)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x, sa = blockIdx.y;
     if (sb >= 766) return;
-    const int delta = edge_delta(sa, sb, t_fix);
+    const float delta = edge_delta((float)sa, (float)sb, neg_t);
     table[sa * 766 + sb] = delta > SM_EDGE_MARGIN ? 1 : delta < -SM_EDGE_MARGIN ? 0
                                                       : edge_from_table(tab, sa, sb);
 }
 
 #define SM_EDGE_ROWS 32   // ext rows one wave walks down
 
+// byte B of a dword as f32 (v_cvt_f32_ubyteB)
+template <int B> __device__ __forceinline__ float cvt_ubyte(u32 q)
+{
+    float f;
+    if (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(q));
+    if (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(q));
+    if (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(q));
+    if (B == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(q));
+    return f;
+}
+
+// One pixel's decision from its 8 orientation sums (f32, exact integers).
+// sa/sb order: left|right, top|bottom, up-left|down-right, down-left|up-right
+// (src/stereo.c:16-70).  `exact` (ghost pixels on or outside the image border,
+// whose sums contain the 128.0 halo and are outside the tables; or no usable
+// tables at all) takes the double arithmetic of the reference.
+template <bool TABLES>
+__device__ __forceinline__ u32 edge_decide(const float (&sa)[4], const float (&sb)[4],
+                                           const u32 *__restrict__ tab, double threshold,
+                                           float neg_t, bool exact)
+{
+    u32 e;
+    if (TABLES) {
+        float dl[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) dl[o] = edge_delta(sa[o], sb[o], neg_t);
+        const float dmax = fmaxf(fmaxf(dl[0], dl[1]), fmaxf(dl[2], dl[3]));
+        e = __float_as_uint(SM_EDGE_MARGIN - dmax) >> 31;                 // dmax > margin
+        // rare: the deciding sum pair is next to the boundary -> ask the table
+        // (never with halo sums: they are not table indices)
+        if (!exact && __builtin_fabsf(dmax) <= SM_EDGE_MARGIN) {
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+                if (dl[o] >= -SM_EDGE_MARGIN)
+                    e |= edge_from_table(tab, (int)sa[o], (int)sb[o]) ? 1u : 0u;
+        }
+    }
+    if (!TABLES || exact) {
+        e = 0;
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+            e |= contrast_test((int)sa[o], (int)sb[o], threshold) ? 1u : 0u;
+    }
+    return e;
+}
+
 // Edge detection straight into the packed ext image.  No LDS, no barrier: a
 // wave owns a strip of 64 ext pixels x SM_EDGE_ROWS ext rows and walks down it;
 // each lane keeps the 3 x 3 gray neighbourhood of its pixel in registers and
-// loads three bytes (x-1, x, x+1) of the next row per step, so the loads of
-// row y+2 are in flight while row y is decided.  The wave's 64 decisions become
-// two ext words via ballot.  Border rule at load time: wrapped coordinates
-// (toroidal) or the 128.0 halo, 32768 in units of 1/256 (ghost).
-//
-// The per-pixel decision is integer arithmetic on purpose (sign bits, no bool
-// short-circuits): compares feeding && / || turn into SGPR-mask traffic, and an
-// earlier version of this kernel was bound by the CU's scalar issue port.
+// loads three bytes (x-1, x, x+1) of the next row per step.  The wave's 64
+// decisions become two ext words via ballot.  Border rule at load time: wrapped
+// coordinates (toroidal) or the 128.0 halo, 32768 in units of 1/256 (ghost).
+// This is the any-width kernel; widths that are a multiple of 4 take
+// k_edges_ext4 below.
 template <bool GHOST, bool TABLES>
 __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
                                                    const u8 *__restrict__ src_r,
@@ -179,7 +221,7 @@ __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
                                                    u8 *__restrict__ edges_r,
                                                    u32 *__restrict__ ext,
                                                    const u32 *__restrict__ tab,
-                                                   const MatchGeom g, double threshold, int t_fix)
+                                                   const MatchGeom g, double threshold, float neg_t)
 {
     const int tid = threadIdx.x;
     const int xe = blockIdx.x * 256 + tid;
@@ -192,6 +234,7 @@ __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
     const int x = xe - g.pad_l;
     const u32 in_x = (xe < g.ext_words * 32 && (!GHOST || (x >= 0 && x < g.w))) ? 1u : 0u;
     const bool store_x = x >= 0 && x < g.w && edges != nullptr;
+    const bool inner_x = x > 0 && x < g.w - 1;             // ghost: no halo in the 3 columns
     u32 *ext_img = ext + (size_t)blockIdx.z * g.ext_rows * g.ext_words;
     const int wd = xe >> 5;
 
@@ -215,19 +258,19 @@ __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
     // rows: image row of ext row ye is ye - half; the walk starts one above
     int y_img = ye0 - g.half - 1;
     int ys = GHOST ? y_img : pos_mod(y_img, g.h);       // source row (toroidal: wrapped)
-    auto load_row = [&](int (&o)[3]) {
+    auto load_row = [&](float (&o)[3]) {
         const bool vy = !GHOST || (y_img >= 0 && y_img < g.h);
         const u8 *row = src + (size_t)(vy ? ys : 0) * g.w;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const int v = row[xc[k]];
-            o[k] = (vy && vx[k]) ? v : 32768;
+            const float v = (float)row[xc[k]];
+            o[k] = (vy && vx[k]) ? v : 32768.0f;
         }
         y_img++;
         ys = GHOST ? y_img : (ys + 1 == g.h ? 0 : ys + 1);
     };
 
-    int v[3][3];          // v[row][col]: row 0 = y-1, col 0 = x-1
+    float v[3][3];          // v[row][col]: row 0 = y-1, col 0 = x-1
     load_row(v[0]);
     load_row(v[1]);
     const int rows = min(SM_EDGE_ROWS, g.ext_rows - ye0);
@@ -236,43 +279,16 @@ __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
         const int ye = ye0 + rr;
         const int y = ye - g.half;
         const bool in_y = y >= 0 && y < g.h;         // uniform
-        const int sa[4] = {v[0][0] + v[1][0] + v[2][0],      // left      src/stereo.c:16-28
-                           v[0][0] + v[0][1] + v[0][2],      // top       src/stereo.c:30-42
-                           v[0][0] + v[0][1] + v[1][0],      // up-left   src/stereo.c:44-56
-                           v[2][0] + v[2][1] + v[1][0]};     // down-left src/stereo.c:58-70
-        const int sb[4] = {v[0][2] + v[1][2] + v[2][2],      // right
-                           v[2][0] + v[2][1] + v[2][2],      // bottom
-                           v[1][2] + v[2][1] + v[2][2],      // down-right
-                           v[0][1] + v[0][2] + v[1][2]};     // up-right
-        u32 e;
-        if (!TABLES) {
-            e = 0;
-#pragma unroll
-            for (int o = 0; o < 4; o++) e |= contrast_test(sa[o], sb[o], threshold) ? 1u : 0u;
-        } else {
-            int dl[4];
-#pragma unroll
-            for (int o = 0; o < 4; o++) dl[o] = edge_delta(sa[o], sb[o], t_fix);
-            const int dmax = max(max(dl[0], dl[1]), max(dl[2], dl[3]));
-            e = (u32)(SM_EDGE_MARGIN - dmax) >> 31;                  // dmax > margin
-            // rare: the deciding sum pair is next to the boundary -> ask the table
-            if ((u32)(dmax + SM_EDGE_MARGIN) <= 2u * SM_EDGE_MARGIN) {
-#pragma unroll
-                for (int o = 0; o < 4; o++)
-                    if (dl[o] >= -SM_EDGE_MARGIN) e |= edge_from_table(tab, sa[o], sb[o]) ? 1u : 0u;
-            }
-            if (GHOST) {
-                // sums that contain the halo (image-border pixels only) are outside
-                // the tables: exact double arithmetic
-                const int smax = max(max(max(sa[0], sb[0]), max(sa[1], sb[1])),
-                                     max(max(sa[2], sb[2]), max(sa[3], sb[3])));
-                if (smax >= 766) {
-                    e = 0;
-#pragma unroll
-                    for (int o = 0; o < 4; o++) e |= contrast_test(sa[o], sb[o], threshold) ? 1u : 0u;
-                }
-            }
-        }
+        const float sa[4] = {v[0][0] + v[1][0] + v[2][0],      // left      src/stereo.c:16-28
+                             v[0][0] + v[0][1] + v[0][2],      // top       src/stereo.c:30-42
+                             v[0][0] + v[0][1] + v[1][0],      // up-left   src/stereo.c:44-56
+                             v[2][0] + v[2][1] + v[1][0]};     // down-left src/stereo.c:58-70
+        const float sb[4] = {v[0][2] + v[1][2] + v[2][2],      // right
+                             v[2][0] + v[2][1] + v[2][2],      // bottom
+                             v[1][2] + v[2][1] + v[2][2],      // down-right
+                             v[0][1] + v[0][2] + v[1][2]};     // up-right
+        const bool exact = GHOST && !(inner_x && y > 0 && y < g.h - 1);
+        const u32 e = edge_decide<TABLES>(sa, sb, tab, threshold, neg_t, exact);
         const u32 val = e & in_x & ((!GHOST || in_y) ? 1u : 0u);
         if (store_x && in_y) edges[img + (size_t)y * g.w + x] = (u8)val;
         const unsigned long long bal = __ballot(val != 0);
@@ -286,12 +302,22 @@ __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
     }
 }
 
-// Same decision, FOUR pixels per lane (images whose width is a multiple of 4):
-// one aligned dword load brings the 4 gray values of a row, two byte loads the
-// neighbours left and right, so a row costs 0.75 loads per pixel instead of 3.
-// A lane's 4 decisions form a nibble; 8 adjacent lanes OR their nibbles
-// together (DPP) into one ext word.
-#define SM_EDGE4_ROWS 8
+// Same decision, FOUR pixels per lane (images whose width is a multiple of 4).
+// Per row a lane loads ONE aligned dword (its 4 gray values); the pixels left
+// and right of the quad are bytes of the neighbouring lanes' dwords, fetched
+// with DPP wave shifts -- only lane 0 / lane 63 of a wave need a real byte load
+// (one instruction serves both).  A wave's whole strip is SM_EDGE4_ROWS + 2
+// rows: ALL its loads are issued before the first decision (the row loop is
+// unrolled over a compile-time row count), so a wave pays the HBM latency once
+// instead of once per row -- the row-at-a-time version of this kernel spent half
+// its wave-cycles waiting.  Sums are shared: per row the 5 pair sums and 4 triple
+// sums of horizontally adjacent pixels are formed once and carried down (the
+// bottom sums of row y are the top sums of row y+2); column sums serve as `left`
+// of one pixel and `right` of another.  A lane's 4 decisions form a nibble; 8
+// adjacent lanes OR their nibbles together (DPP) into one ext word.
+#ifndef SM_EDGE4_ROWS
+#define SM_EDGE4_ROWS 4
+#endif
 template <bool GHOST, bool TABLES>
 __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l,
                                                     const u8 *__restrict__ src_r,
@@ -299,11 +325,13 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
                                                     u8 *__restrict__ edges_r,
                                                     u32 *__restrict__ ext,
                                                     const u32 *__restrict__ tab,
-                                                    const MatchGeom g, double threshold, int t_fix)
+                                                    const MatchGeom g, double threshold, float neg_t)
 {
+    constexpr int R = SM_EDGE4_ROWS;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int xe = (blockIdx.x * 256 + tid) * 4;          // first of this lane's 4 ext pixels
-    const int ye0 = blockIdx.y * SM_EDGE4_ROWS;
+    const int ye0 = blockIdx.y * R;
     const int pair = blockIdx.z >> 1, side = blockIdx.z & 1;
     const size_t img = (size_t)pair * g.w * g.h;
     const u8 *src = (side ? src_r : src_l) + img;
@@ -312,88 +340,96 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
     const int x = xe - g.pad_l;                            // multiple of 4
     const bool in_ext = xe < g.ext_words * 32;
     const bool quad_in = x >= 0 && x < g.w;                // all 4 inside (w % 4 == 0)
+    const bool inner_x = x > 0 && x + 4 < g.w;             // ghost: no halo in the 6 columns
     u32 *ext_img = ext + (size_t)blockIdx.z * g.ext_rows * g.ext_words;
     const int wd = xe >> 5;
 
-    // source columns: the aligned quad, and the single pixels left and right of it
-    int xq, xl, xr;
+    // source columns: the aligned quad; the single pixel left (lane 0) or right
+    // (lane 63) of the wave's span -- the other lanes' value of `xn` is unused
+    int xq, xn;
     bool vq, vl, vr;
     if (GHOST) {
         vq = quad_in; vl = x - 1 >= 0 && x - 1 < g.w; vr = x + 4 >= 0 && x + 4 < g.w;
-        xq = vq ? x : 0; xl = vl ? x - 1 : 0; xr = vr ? x + 4 : 0;
+        xq = vq ? x : 0;
+        xn = lane == 63 ? (vr ? x + 4 : 0) : (vl ? x - 1 : 0);
     } else {
         xq = pos_mod(x, g.w);
-        xl = xq == 0 ? g.w - 1 : xq - 1;
-        xr = xq + 4 == g.w ? 0 : xq + 4;
+        xn = lane == 63 ? (xq + 4 == g.w ? 0 : xq + 4) : (xq == 0 ? g.w - 1 : xq - 1);
         vq = vl = vr = true;
     }
 
-    int y_img = ye0 - g.half - 1;
-    int ys = GHOST ? y_img : pos_mod(y_img, g.h);
-    auto load_row = [&](int (&o)[6]) {
-        const bool vy = !GHOST || (y_img >= 0 && y_img < g.h);
-        const u8 *row = src + (size_t)(vy ? ys : 0) * g.w;
-        const u32 q4 = *reinterpret_cast<const u32 *>(row + xq);
-        const int l = row[xl], r = row[xr];
-        o[0] = (vy && vl) ? l : 32768;
+    // all loads of the strip: rows ye0-half-1 ... ye0-half+R (border rule on the row)
+    u32 q4[R + 2], nb[R + 2];
+    bool vy[R + 2];
+    {
+        int y_img = ye0 - g.half - 1;
+        int ys = GHOST ? y_img : pos_mod(y_img, g.h);
 #pragma unroll
-        for (int k = 0; k < 4; k++) o[1 + k] = (vy && vq) ? (int)((q4 >> (8 * k)) & 255u) : 32768;
-        o[5] = (vy && vr) ? r : 32768;
-        y_img++;
-        ys = GHOST ? y_img : (ys + 1 == g.h ? 0 : ys + 1);
+        for (int k = 0; k < R + 2; k++) {
+            vy[k] = !GHOST || (y_img >= 0 && y_img < g.h);
+            const u8 *row = src + (size_t)(vy[k] ? ys : 0) * g.w;
+            q4[k] = *reinterpret_cast<const u32 *>(row + xq);
+            nb[k] = row[xn];
+            y_img++;
+            ys = GHOST ? y_img : (ys + 1 == g.h ? 0 : ys + 1);
+        }
+    }
+    // gray values of a row as f32 (col 0 = x-1 ... col 5 = x+4), its pair and triple sums
+    auto unpack_row = [&](int k, float (&o)[6], float (&p)[5], float (&s3)[4]) {
+        const u32 q = q4[k];
+        // lane i-1's / lane i+1's dword (wave_shr:1 / wave_shl:1)
+        const u32 from_l = (u32)__builtin_amdgcn_update_dpp(0, (int)q, 0x138, 0xf, 0xf, false);
+        const u32 from_r = (u32)__builtin_amdgcn_update_dpp(0, (int)q, 0x130, 0xf, 0xf, false);
+        const u32 lq = lane == 0 ? nb[k] << 24 : from_l;
+        const u32 rq = lane == 63 ? nb[k] : from_r;
+        // v_cvt_f32_ubyteN: byte -> f32 in one instruction, and opaque to the
+        // optimiser (plain casts get their f32 sums folded back into integer adds
+        // plus one conversion per SUM, which is more work)
+        const float g0 = cvt_ubyte<0>(q), g1 = cvt_ubyte<1>(q),
+                    g2 = cvt_ubyte<2>(q), g3 = cvt_ubyte<3>(q);
+        const bool okq = vy[k] && vq;
+        o[0] = (vy[k] && vl) ? cvt_ubyte<3>(lq) : 32768.0f;
+        o[1] = okq ? g0 : 32768.0f;
+        o[2] = okq ? g1 : 32768.0f;
+        o[3] = okq ? g2 : 32768.0f;
+        o[4] = okq ? g3 : 32768.0f;
+        o[5] = (vy[k] && vr) ? cvt_ubyte<0>(rq) : 32768.0f;
+#pragma unroll
+        for (int c = 0; c < 5; c++) p[c] = o[c] + o[c + 1];
+#pragma unroll
+        for (int c = 0; c < 4; c++) s3[c] = p[c] + o[c + 2];
     };
 
-    int v[3][6];          // v[row][col]: row 0 = y-1, col 0 = x-1 ... col 5 = x+4
-    load_row(v[0]);
-    load_row(v[1]);
-    const int rows = min(SM_EDGE4_ROWS, g.ext_rows - ye0);
-    for (int rr = 0; rr < rows; rr++) {
-        load_row(v[2]);
+    float v[3][6], p[3][5], s3[3][4];      // [row][col]: row 0 = y-1
+    unpack_row(0, v[0], p[0], s3[0]);
+    unpack_row(1, v[1], p[1], s3[1]);
+#pragma unroll
+    for (int rr = 0; rr < R; rr++) {
+        unpack_row(rr + 2, v[2], p[2], s3[2]);
         const int ye = ye0 + rr;
         const int y = ye - g.half;
         const bool in_y = y >= 0 && y < g.h;         // uniform
+        const bool exact = GHOST && !(inner_x && y > 0 && y < g.h - 1);
+        float col[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) col[k] = v[0][k] + v[1][k] + v[2][k];
         u32 nib = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             // 3x3 neighbourhood of pixel q: columns q, q+1, q+2 of v
-            const int sa[4] = {v[0][q] + v[1][q] + v[2][q],              // left      src/stereo.c:16-28
-                               v[0][q] + v[0][q + 1] + v[0][q + 2],      // top       src/stereo.c:30-42
-                               v[0][q] + v[0][q + 1] + v[1][q],          // up-left   src/stereo.c:44-56
-                               v[2][q] + v[2][q + 1] + v[1][q]};         // down-left src/stereo.c:58-70
-            const int sb[4] = {v[0][q + 2] + v[1][q + 2] + v[2][q + 2],  // right
-                               v[2][q] + v[2][q + 1] + v[2][q + 2],      // bottom
-                               v[1][q + 2] + v[2][q + 1] + v[2][q + 2],  // down-right
-                               v[0][q + 1] + v[0][q + 2] + v[1][q + 2]}; // up-right
-            u32 e;
-            if (!TABLES) {
-                e = 0;
-#pragma unroll
-                for (int o = 0; o < 4; o++) e |= contrast_test(sa[o], sb[o], threshold) ? 1u : 0u;
-            } else {
-                int dl[4];
-#pragma unroll
-                for (int o = 0; o < 4; o++) dl[o] = edge_delta(sa[o], sb[o], t_fix);
-                const int dmax = max(max(dl[0], dl[1]), max(dl[2], dl[3]));
-                e = (u32)(SM_EDGE_MARGIN - dmax) >> 31;
-                if ((u32)(dmax + SM_EDGE_MARGIN) <= 2u * SM_EDGE_MARGIN) {
-#pragma unroll
-                    for (int o = 0; o < 4; o++)
-                        if (dl[o] >= -SM_EDGE_MARGIN) e |= edge_from_table(tab, sa[o], sb[o]) ? 1u : 0u;
-                }
-                if (GHOST) {
-                    const int smax = max(max(max(sa[0], sb[0]), max(sa[1], sb[1])),
-                                         max(max(sa[2], sb[2]), max(sa[3], sb[3])));
-                    if (smax >= 766) {
-                        e = 0;
-#pragma unroll
-                        for (int o = 0; o < 4; o++) e |= contrast_test(sa[o], sb[o], threshold) ? 1u : 0u;
-                    }
-                }
-            }
-            nib |= e << q;
+            const float sa[4] = {col[q],                       // left      src/stereo.c:16-28
+                                 s3[0][q],                     // top       src/stereo.c:30-42
+                                 p[0][q] + v[1][q],            // up-left   src/stereo.c:44-56
+                                 p[2][q] + v[1][q]};           // down-left src/stereo.c:58-70
+            const float sb[4] = {col[q + 2],                   // right
+                                 s3[2][q],                     // bottom
+                                 p[2][q + 1] + v[1][q + 2],    // down-right
+                                 p[0][q + 1] + v[1][q + 2]};   // up-right
+            nib |= edge_decide<TABLES>(sa, sb, tab, threshold, neg_t, exact) << q;
         }
         if (!in_ext || (GHOST && !(quad_in && in_y))) nib = 0;
-        if (edges != nullptr && quad_in && in_y) {
+        const bool row_ok = ye < g.ext_rows;         // uniform; the last strip may be short
+        if (edges != nullptr && quad_in && in_y && row_ok) {
             // u8 {0,1} per pixel: bit q of the nibble -> byte q
             const u32 bytes = __umul24(nib, 0x204081u) & 0x01010101u;
             *reinterpret_cast<u32 *>(edges + img + (size_t)y * g.w + x) = bytes;
@@ -403,9 +439,13 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
         wv |= (u32)__builtin_amdgcn_update_dpp(0, (int)wv, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
         wv |= (u32)__builtin_amdgcn_update_dpp(0, (int)wv, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
         wv |= (u32)__builtin_amdgcn_update_dpp(0, (int)wv, 0x141, 0xf, 0xf, true);   // row_half_mirror
-        if ((tid & 7) == 0 && wd < g.ext_words) ext_img[(size_t)ye * g.ext_words + wd] = wv;
+        if ((tid & 7) == 0 && wd < g.ext_words && row_ok) ext_img[(size_t)ye * g.ext_words + wd] = wv;
 #pragma unroll
         for (int k = 0; k < 6; k++) { v[0][k] = v[1][k]; v[1][k] = v[2][k]; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) { p[0][k] = p[1][k]; p[1][k] = p[2][k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { s3[0][k] = s3[1][k]; s3[1][k] = s3[2][k]; }
     }
 }
 
@@ -773,9 +813,9 @@ static int pack_ext(sm_plan *plan, const u8 *l, const u8 *r, int pairs, hipStrea
     return SM_OK;
 }
 
-static int edge_t_fix(double threshold)
+static float edge_neg_t(double threshold)
 {
-    return (int)(threshold * 0.5 * (double)(1 << SM_EDGE_FIX) + 0.5);
+    return -(float)(threshold * 0.5);
 }
 
 // decision tables depend on the threshold only: rebuilt when it changes
@@ -807,7 +847,7 @@ extern "C" int sm_debug_edge_table_fast(sm_plan *plan, double threshold, uint8_t
     hipStream_t st = (hipStream_t)stream;
     SM_TRY(ensure_edge_tables(plan, threshold, st));
     hipLaunchKernelGGL(k_edge_table_fast, dim3(3, 766), dim3(256), 0, st, plan->d_edge_tab,
-                       edge_t_fix(threshold), d_table);
+                       edge_neg_t(threshold), d_table);
     SM_LAUNCH_CHECK("k_edge_table_fast");
     i32 bad = 0;
     SM_HIP(hipMemcpyAsync(&bad, &plan->d_flags[2], sizeof(i32), hipMemcpyDeviceToHost, st));
@@ -838,7 +878,7 @@ extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
 #define SM_EDGES_GO(G, T)                                                                      \
     hipLaunchKernelGGL((k_edges_ext4<G, T>), grid4, block, 0, st, d_gray_left, d_gray_right,     \
                        d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab, g, threshold, \
-                       edge_t_fix(threshold))
+                       edge_neg_t(threshold))
         if (plan->tab_ok) { if (ghost) SM_EDGES_GO(true, true); else SM_EDGES_GO(false, true); }
         else              { if (ghost) SM_EDGES_GO(true, false); else SM_EDGES_GO(false, false); }
 #undef SM_EDGES_GO
@@ -846,7 +886,7 @@ extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
 #define SM_EDGES_GO(G, T)                                                                      \
     hipLaunchKernelGGL((k_edges_ext<G, T>), grid, block, 0, st, d_gray_left, d_gray_right,       \
                        d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab, g, threshold, \
-                       edge_t_fix(threshold))
+                       edge_neg_t(threshold))
         if (plan->tab_ok) { if (ghost) SM_EDGES_GO(true, true); else SM_EDGES_GO(false, true); }
         else              { if (ghost) SM_EDGES_GO(true, false); else SM_EDGES_GO(false, false); }
 #undef SM_EDGES_GO

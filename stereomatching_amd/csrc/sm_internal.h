@@ -91,13 +91,16 @@ struct sm_plan {
 // packed image themselves, be fetched into one L2 instead of eight.  Bijective for
 // any tile count (MI355X guide, T1); placement is a speed matter only.
 #ifdef __HIPCC__
+// linear workgroup id -> position in an XCD-contiguous order over n items
+__device__ __forceinline__ int sm_xcd_order(int lin, int n)
+{
+    const int xcd = lin & 7, j = lin >> 3;
+    const int q = n >> 3, r = n & 7;                  // r XCDs get q + 1 items
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
 __device__ __forceinline__ void sm_xcd_tile(int tiles_x, int tiles_y, int &tx, int &ty)
 {
-    const int n = tiles_x * tiles_y;
-    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const int xcd = lin & 7, j = lin >> 3;
-    const int q = n >> 3, r = n & 7;                  // r XCDs get q + 1 tiles
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int t = sm_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, tiles_x * tiles_y);
     ty = t / tiles_x;
     tx = t - ty * tiles_x;
 }

@@ -182,7 +182,10 @@ def test_edge_threshold_tables_exhaustive(hip):
 @pytest.mark.parametrize("w,h,kind,thr", [
     (64, 48, "scene", 0.15), (301, 97, "scene", 0.15), (130, 77, "noise", 0.5),
     (40, 40, "noise", 0.0), (55, 33, "scene", 1.0), (3, 3, "noise", 0.15),
-    (1, 9, "noise", 0.15), (9, 1, "noise", 0.15), (2, 2, "noise", 0.3), (512, 64, "constant", 0.15)])
+    (1, 9, "noise", 0.15), (9, 1, "noise", 0.15), (2, 2, "noise", 0.3), (512, 64, "constant", 0.15),
+    # 4-pixel-per-lane kernel across wave and workgroup seams (neighbour pixels via DPP,
+    # real loads only at lanes 0 / 63), with ties (threshold 0 sends pixels to the tables)
+    (1284, 21, "noise", 0.15), (772, 13, "noise", 0.0), (2052, 9, "scene", 0.075), (4, 7, "noise", 0.2)])
 def test_edges_match_oracle(hip, mode, w, h, kind, thr):
     left, right = make_pair(w, h, 16, seed=w + h, kind=kind)
     sw = min(5, w, h)
