@@ -58,6 +58,7 @@ _SIGNATURES = {
     "sm_match_wta": (_int, [_vp, _int, _vp, _vp, _vp]),
     "sm_plan_set_pipelined": (_int, [_vp, _int]),
     "sm_plan_time_kernels": (_int, [_vp, _int]),
+    "sm_plan_time_stride": (_int, [_vp, _int]),
     "sm_plan_kernel_ms": (_int, [_vp, C.POINTER(C.c_double), _intp]),
     "sm_run": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp]),
     "sm_cost_wta": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp, _vp]),

@@ -353,7 +353,12 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
         xq = vq ? x : 0;
         xn = lane == 63 ? (vr ? x + 4 : 0) : (vl ? x - 1 : 0);
     } else {
-        xq = pos_mod(x, g.w);
+        // x is in [-pad_l, ext width - pad_l): one conditional add or subtract wraps it
+        // whenever the image is at least as wide as either pad (the usual case);
+        // the division is the fallback for images narrower than their padding
+        const int over = g.ext_words * 32 - g.pad_l - g.w;     // uniform: columns right of the image
+        if (g.w >= g.pad_l && g.w >= over) xq = x < 0 ? x + g.w : (x >= g.w ? x - g.w : x);
+        else                               xq = pos_mod(x, g.w);
         xn = lane == 63 ? (xq + 4 == g.w ? 0 : xq + 4) : (xq == 0 ? g.w - 1 : xq - 1);
         vq = vl = vr = true;
     }
@@ -716,6 +721,7 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
     SM_TRY(use_device(device));
 
     sm_plan *p = (sm_plan *)calloc(1, sizeof *p);
+    if (p) p->timing_every = 1;
     if (!p) return sm_fail(SM_ERR_NOMEM, "error: out of memory");
     p->device = device;
     p->width = width; p->height = height;
@@ -915,13 +921,21 @@ extern "C" int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d
         return sm_fail(SM_ERR_ARG, "sm_match_wta: %d pairs requested but edges of only %d are loaded "
                        "(call sm_find_edges or sm_load_edges first)", pairs, plan->pairs_loaded);
     SM_TRY(use_device(plan->device));
-    const bool timed = plan->timing_n < plan->timing_cap;
+    // event records are not free (~4 us each on the launch stream): time a sample of
+    // the launches, and record the buffer-release event only when someone can wait on it
+    const bool timed = plan->timing_n < plan->timing_cap &&
+                       plan->timing_seen++ % plan->timing_every == 0;
     if (timed) SM_HIP(hipEventRecord(plan->t_begin[plan->timing_n], (hipStream_t)stream));
     SM_TRY(sm_match_launch(plan, pairs, d_web, d_best, (hipStream_t)stream));
     if (timed) SM_HIP(hipEventRecord(plan->t_end[plan->timing_n++], (hipStream_t)stream));
-    // a later pipelined sm_run must not overwrite this buffer before the launch has read it
-    SM_HIP(hipEventRecord(plan->ev_free[plan->cur], (hipStream_t)stream));
-    plan->ev_free_set[plan->cur] = 1;
+    if (plan->pipelined) {
+        // the next-but-one sm_run must not overwrite this buffer before the launch has read it
+        SM_HIP(hipEventRecord(plan->ev_free[plan->cur], (hipStream_t)stream));
+        plan->ev_free_set[plan->cur] = 1;
+    } else {
+        plan->ev_free_set[plan->cur] = 0;
+        plan->unfenced = 1;                // launches a later pipelined phase has no event for
+    }
     return SM_OK;
 }
 
@@ -942,6 +956,7 @@ extern "C" int sm_plan_time_kernels(sm_plan *plan, int capacity)
     if (!plan || capacity < 0 || capacity > (1 << 20))
         return sm_fail(SM_ERR_ARG, "sm_plan_time_kernels: bad argument");
     SM_TRY(use_device(plan->device));
+    plan->timing_seen = 0;
     if (capacity == plan->timing_cap) { plan->timing_n = 0; return SM_OK; }
     free_timing(plan);
     if (capacity == 0) return SM_OK;
@@ -953,6 +968,14 @@ extern "C" int sm_plan_time_kernels(sm_plan *plan, int capacity)
         SM_HIP(hipEventCreate(&plan->t_end[i]));
         plan->timing_cap = i + 1;
     }
+    return SM_OK;
+}
+
+extern "C" int sm_plan_time_stride(sm_plan *plan, int every)
+{
+    if (!plan || every < 1) return sm_fail(SM_ERR_ARG, "sm_plan_time_stride: bad argument");
+    plan->timing_every = every;
+    plan->timing_seen = 0;
     return SM_OK;
 }
 
@@ -990,6 +1013,13 @@ extern "C" int sm_run(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *
     // previous call's match is NOT reading
     SM_TRY(use_device(plan->device));
     const int b = plan->cur ^ 1;
+    if (plan->unfenced) {
+        // match launches of a non-pipelined phase left no release events: order the
+        // internal stream behind everything already on `stream`, once
+        SM_HIP(hipEventRecord(plan->ev_free[b], (hipStream_t)stream));
+        plan->ev_free_set[b] = 1;
+        plan->unfenced = 0;
+    }
     if (plan->ev_free_set[b]) SM_HIP(hipStreamWaitEvent(plan->edge_stream, plan->ev_free[b], 0));
     plan->cur = b;
     plan->d_ext = plan->d_ext_buf[b];

@@ -71,8 +71,9 @@ struct sm_plan {
     hipEvent_t ev_edges[2];      // edges written into buffer b
     hipEvent_t ev_free[2];       // last match reading buffer b has finished
     int ev_free_set[2];
+    int unfenced;                // match launches went out without a release event
     // optional timing of the match launches (sm_plan_time_kernels)
-    int timing_cap, timing_n;
+    int timing_cap, timing_n, timing_every, timing_seen;
     hipEvent_t *t_begin, *t_end;
     i32 *d_flags;        // [0] = zero-interval flag, [1] = has-zero scratch,
                          // [2] = edge table is not of threshold form

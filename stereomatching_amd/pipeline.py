@@ -76,7 +76,10 @@ class StereoPlan:
         call i).  The inputs given to run() must be complete in memory at call time."""
         check(lib.sm_plan_set_pipelined(self._h, int(enabled)))
 
-    def time_kernels(self, capacity: int):
+    def time_kernels(self, capacity: int, every: int = 1):
+        """Bracket every `every`-th of the coming match launches (at most `capacity` of
+        them) with HIP events on the launch stream."""
+        check(lib.sm_plan_time_stride(self._h, int(every)))
         check(lib.sm_plan_time_kernels(self._h, int(capacity)))
 
     def kernel_ms(self):

@@ -375,6 +375,16 @@ def test_pipelined_runs_and_kernel_timing(hip):
     # and the oracle agrees with the first one
     o = oracle.pipeline(*pairs[0], 0.15, d, sw, step3=False)
     assert np.array_equal(want[0], o["web-1"])
+    # sampled timing: every 3rd of 10 launches, at most 4 of them; back to sequential runs
+    plan.set_pipelined(False)
+    plan.time_kernels(4, every=3)
+    for i in range(10):
+        got = plan.run(*inputs[i % len(inputs)], 0.15)[0]
+        assert np.array_equal(host(got)[0], want[i % len(inputs)])
+    ms, n = plan.kernel_ms()
+    assert n == 4 and ms > 0
+    with pytest.raises(hip.capi.StereoHipError, match="sm_plan_time_stride"):
+        plan.time_kernels(4, every=0)
     plan.time_kernels(0)
     plan.close()
 

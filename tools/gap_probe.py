@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Where the step time goes beyond the two kernels: event-record overhead of
+sm_plan_time_kernels, and launch gaps with / without a HIP graph (one device)."""
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from stereomatching_amd import pipeline as hip  # noqa: E402
+from stereomatching_amd.capi import check, lib  # noqa: E402
+from stereomatching_amd.synth import CONFIGS, make_pair  # noqa: E402
+
+w, h, d, sw, mode = CONFIGS["C3"]
+left, right = make_pair(w, h, d, seed=1)
+L = torch.from_numpy(left).cuda()[None].contiguous()
+R = torch.from_numpy(right).cuda()[None].contiguous()
+web = torch.empty((1, h, w), dtype=torch.int32, device="cuda")
+plan = hip.StereoPlan(w, h, d, sw, mode)
+s = torch.cuda.Stream()
+N = 200
+
+
+def run(n, stream):
+    for _ in range(n):
+        check(lib.sm_run(plan._h, C.c_void_p(L.data_ptr()), C.c_void_p(R.data_ptr()), 0.15, 1,
+                         C.c_void_p(web.data_ptr()), None, C.c_void_p(stream.cuda_stream)))
+
+
+def timed(label, fn):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / N * 1e6)
+    print(f"{label:40s} {best:8.2f} us/step")
+
+
+with torch.cuda.stream(s):
+    plan.time_kernels(0)
+    timed("stream launches, no events", lambda: run(N, s))
+    plan.time_kernels(N)
+    def with_events():
+        plan.time_kernels(N); run(N, s)
+    timed("stream launches, events around match", with_events)
+    print("   kernel_ms", plan.kernel_ms())
+    plan.time_kernels(0)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        run(20, s)
+    timed("graph of 20 steps x 10 replays", lambda: [g.replay() for _ in range(N // 20)])
