@@ -102,14 +102,15 @@ __device__ __forceinline__ void add_planes(u32 (&s)[SB], const u32 (&h)[HB])
     s[0] ^= h[0];
 #pragma unroll
     for (int k = 1; k < SB; k++) {
+        // carry first, then the plane in place: a sum plane stays in its register
         if (k < HB) {
-            const u32 t = bop<BOP_XOR3>(s[k], h[k], c);
-            c = bop<BOP_MAJ>(s[k], h[k], c);
-            s[k] = t;
+            const u32 cn = bop<BOP_MAJ>(s[k], h[k], c);
+            s[k] = bop<BOP_XOR3>(s[k], h[k], c);
+            c = cn;
         } else {
-            const u32 t = s[k] ^ c;
-            if (k + 1 < SB) c = s[k] & c;
-            s[k] = t;
+            const u32 cn = k + 1 < SB ? s[k] & c : 0u;
+            s[k] ^= c;
+            c = cn;
         }
     }
 }
@@ -123,13 +124,13 @@ __device__ __forceinline__ void sub_planes(u32 (&s)[SB], const u32 (&h)[HB])
 #pragma unroll
     for (int k = 1; k < SB; k++) {
         if (k < HB) {
-            const u32 t = bop<BOP_XOR3>(s[k], h[k], b);
-            b = bop<BOP_BORROW>(s[k], h[k], b);
-            s[k] = t;
+            const u32 bn = bop<BOP_BORROW>(s[k], h[k], b);
+            s[k] = bop<BOP_XOR3>(s[k], h[k], b);
+            b = bn;
         } else {
-            const u32 t = s[k] ^ b;
-            if (k + 1 < SB) b = ~s[k] & b;
-            s[k] = t;
+            const u32 bn = k + 1 < SB ? ~s[k] & b : 0u;
+            s[k] ^= b;
+            b = bn;
         }
     }
 }
@@ -153,9 +154,9 @@ __device__ __forceinline__ void addsub_planes(u32 (&s)[SB], const u32 (&hn)[HB],
 #pragma unroll
     for (int k = 1; k < SB; k++) {
         const u32 a = k < HB ? dl[k] : sg;
-        const u32 t = bop<BOP_XOR3>(s[k], a, c);
-        if (k + 1 < SB) c = bop<BOP_MAJ>(s[k], a, c);
-        s[k] = t;
+        const u32 cn = k + 1 < SB ? bop<BOP_MAJ>(s[k], a, c) : 0u;
+        s[k] = bop<BOP_XOR3>(s[k], a, c);
+        c = cn;
     }
 }
 
@@ -320,23 +321,25 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
         }
     };
 
+    // staged row e is image row ty0 - HALF + e; ghost rows outside the image hold no
+    // valid tap: nothing to add or remove
+    auto row_valid = [&](int e) {
+        const int yy = ty0 - HALF + e;
+        return !GHOST || (yy >= 0 && yy < g.h);
+    };
     const int rows_out = min(g.tile_h, g.h - ty0);
-    const int steps = rows_out + N - 1;
-    for (int e = 0; e < steps; e++) {
-        // staged row e is image row ty0 - HALF + e; ghost rows outside the image
-        // hold no valid tap: nothing to add or remove
-        {
-            const int y_new = ty0 - HALF + e, y_old = y_new - N;
-            const bool has_new = !GHOST || (y_new >= 0 && y_new < g.h);
-            const bool has_old = e >= N && (!GHOST || (y_old >= 0 && y_old < g.h));
-            if (has_new && has_old) slide_both(e, e - N);
-            else if (has_new) slide(e, true);
-            else if (has_old) slide(e - N, false);
-        }
-        if (e < N - 1) continue;
 
+    // ---- warm-up: the N window rows of output row 0.  A loop of its own, so that the
+    // steady-state loop below has ONE code path updating S (with both in one loop the
+    // register allocator met two definitions of every sum plane at the join and paid
+    // 16 x SB register copies per row for it).
+#pragma unroll 1
+    for (int e = 0; e < N; e++)
+        if (row_valid(e)) slide(e, true);
+
+#pragma unroll 1
+    for (int t = 0;;) {
         // ---- winner-take-all of output row t over this lane's 16 shifts
-        const int t = e - (N - 1);
         const int y = ty0 + t;
         const u32 lc = pL[(t + HALF) * plw + wLc];
         const u32 *rrc = pR + (t + HALF) * prw + wRc;
@@ -436,6 +439,20 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
                             if (best) best[o + q] = bv[q];
                         }
                 }
+            }
+        }
+
+        // ---- slide the window down: staged row t + N - 1 in, staged row t - 1 out
+        if (++t >= rows_out) break;
+        {
+            const int e_new = t + N - 1, e_old = t - 1;
+            if (!GHOST) {
+                slide_both(e_new, e_old);
+            } else {
+                const bool has_new = row_valid(e_new), has_old = row_valid(e_old);
+                if (has_new && has_old) slide_both(e_new, e_old);
+                else if (has_new) slide(e_new, true);
+                else if (has_old) slide(e_old, false);
             }
         }
     }
