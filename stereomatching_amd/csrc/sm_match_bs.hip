@@ -115,26 +115,6 @@ __device__ __forceinline__ void add_planes(u32 (&s)[SB], const u32 (&h)[HB])
     }
 }
 
-// s -= h  (never negative)
-template <int SB, int HB>
-__device__ __forceinline__ void sub_planes(u32 (&s)[SB], const u32 (&h)[HB])
-{
-    u32 b = ~s[0] & h[0];
-    s[0] ^= h[0];
-#pragma unroll
-    for (int k = 1; k < SB; k++) {
-        if (k < HB) {
-            const u32 bn = bop<BOP_BORROW>(s[k], h[k], b);
-            s[k] = bop<BOP_XOR3>(s[k], h[k], b);
-            b = bn;
-        } else {
-            const u32 bn = k + 1 < SB ? ~s[k] & b : 0u;
-            s[k] ^= b;
-            b = bn;
-        }
-    }
-}
-
 // s += hn - ho in one pass: the HB-plane difference in two's complement (its sign is
 // the borrow out), then one ripple add of the sign-extended difference
 template <int SB, int HB>
@@ -283,8 +263,8 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
         count_bits<N, HB>(x, h);
     };
 
-    // one window row into (add) or out of (sub) all sums
-    auto slide = [&](int srow, bool add) {
+    // warm-up: one window row into all sums
+    auto slide_in = [&](int srow) {
         RowViews v;
         load_views(srow, v);
         u32 win[N];
@@ -297,7 +277,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
             win[N - 1] = rview(v, dd + N - 1);
             u32 h[HB];
             count_row(v, win, h);
-            if (add) add_planes<SB, HB>(S[dd], h); else sub_planes<SB, HB>(S[dd], h);
+            add_planes<SB, HB>(S[dd], h);
         }
     };
     // steady state: one row in and one row out, applied as a single signed difference
@@ -321,12 +301,10 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
         }
     };
 
-    // staged row e is image row ty0 - HALF + e; ghost rows outside the image hold no
-    // valid tap: nothing to add or remove
-    auto row_valid = [&](int e) {
-        const int yy = ty0 - HALF + e;
-        return !GHOST || (yy >= 0 && yy < g.h);
-    };
+    // Staged row e is image row ty0 - HALF + e.  Ghost rows outside the image need no
+    // special case: their ext rows are all zero in BOTH images, so every tap reads
+    // 0 ^ 0 = "no mismatch" and the row adds nothing to the sums (the taps that may
+    // count are taken care of at the output: best = valid taps - mismatches).
     const int rows_out = min(g.tile_h, g.h - ty0);
 
     // ---- warm-up: the N window rows of output row 0.  A loop of its own, so that the
@@ -334,8 +312,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     // register allocator met two definitions of every sum plane at the join and paid
     // 16 x SB register copies per row for it).
 #pragma unroll 1
-    for (int e = 0; e < N; e++)
-        if (row_valid(e)) slide(e, true);
+    for (int e = 0; e < N; e++) slide_in(e);
 
 #pragma unroll 1
     for (int t = 0;;) {
@@ -444,17 +421,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
 
         // ---- slide the window down: staged row t + N - 1 in, staged row t - 1 out
         if (++t >= rows_out) break;
-        {
-            const int e_new = t + N - 1, e_old = t - 1;
-            if (!GHOST) {
-                slide_both(e_new, e_old);
-            } else {
-                const bool has_new = row_valid(e_new), has_old = row_valid(e_old);
-                if (has_new && has_old) slide_both(e_new, e_old);
-                else if (has_new) slide(e_new, true);
-                else if (has_old) slide(e_old, false);
-            }
-        }
+        slide_both(t + N - 1, t - 1);
     }
 }
 
