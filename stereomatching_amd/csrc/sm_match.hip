@@ -588,6 +588,28 @@ int sm_match_configure(sm_plan *plan)
         o.tiles_y = ceil_div(H, th);
         o.nsr = th + o.n - 1;
         o.lds_bytes = o.nsr * rows_words * 4;
+        // A grid that fits the chip in one round must also be SPREAD evenly: where the
+        // registers allow more resident workgroups than the round needs (7x7: 12 per CU,
+        // 8 needed) the dispatcher may stack 3 waves on some SIMDs and leave others with
+        // 1, and the launch then lasts as long as the crowded ones (measured at 8 x 1080p:
+        // 100 us spread evenly, 124 us not).  Cap the residency at what the round needs
+        // by asking for a larger LDS allocation than the tile uses: LDS per workgroup in
+        // (160 KB / (cap + 1), 160 KB / cap] admits exactly `cap` workgroups per CU.
+        if (bs) {
+            const long long tiles = (long long)o.tiles_x * o.tiles_y * plan->max_pairs;
+            const int cap = (int)((tiles + cus - 1) / cus);
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, o.threads, o.lds_bytes) == hipSuccess
+                && cap >= 2 && cap < per_cu) {
+                const int lds_cu = 160 * 1024, granule = 1280;
+                int want = std::min(64 * 1024, lds_cu / cap / granule * granule);
+                int got = 0;
+                if (want > o.lds_bytes &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, kfn, o.threads, want) == hipSuccess &&
+                    got == cap)
+                    o.lds_bytes = want;
+            }
+        }
         o.ext_words = (o.tiles_x - 1) * (o.tw / 32) + o.prw;
         o.ext_rows = o.tiles_y * th + o.n - 1;
         o.ext_image_words = (long long)o.ext_words * o.ext_rows;

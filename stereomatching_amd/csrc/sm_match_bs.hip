@@ -377,13 +377,16 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
             for (int c = 0; c < per; c += 4) {
                 const int p0 = s * per + c;
                 u32 bb = 0, bhi = 0, alo = 0, ahi = 0;
+                if (best) {                          // uniform: the counts are wanted at all
 #pragma unroll
-                for (int k = 0; k < SB; k++) {
-                    const u32 sp = __umul24((B[k] >> p0) & cmask, 0x204081u) & 0x01010101u;
-                    if (k < 8) bb += sp << k; else bhi += sp << (k - 8);
+                    for (int k = 0; k < SB; k++) {
+                        const u32 sp = __umul24((B[k] >> p0) & cmask, 0x204081u) & 0x01010101u;
+                        if (k < 8) bb += sp << k; else bhi += sp << (k - 8);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < ABMAX; k++) {
+                    if (k >= AB && k >= AB + g.log2nl) continue;   // uniform: planes no merge level set
                     const u32 sp = __umul24((arg[k] >> p0) & cmask, 0x204081u) & 0x01010101u;
                     if (k < 8) alo += sp << k; else ahi += sp << (k - 8);
                 }
@@ -406,8 +409,15 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
                 const int x = x0 + p0;
                 const size_t o = ((size_t)pair * g.h + y) * g.w + x;
                 if (cw == 4 && g.vec_ok && x + 4 <= g.w) {
-                    *reinterpret_cast<int4 *>(web + o) = make_int4(wv[0], wv[1], wv[2], wv[3]);
-                    if (best) *reinterpret_cast<int4 *>(best + o) = make_int4(bv[0], bv[1], bv[2], bv[3]);
+                    // streaming stores: the maps are written once and never read here; kept
+                    // write-back in L2 they are flushed in one burst when the kernel ends
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    const v4i wq = {wv[0], wv[1], wv[2], wv[3]};
+                    __builtin_nontemporal_store(wq, reinterpret_cast<v4i *>(web + o));
+                    if (best) {
+                        const v4i bq = {bv[0], bv[1], bv[2], bv[3]};
+                        __builtin_nontemporal_store(bq, reinterpret_cast<v4i *>(best + o));
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; q++)

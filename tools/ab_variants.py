@@ -59,7 +59,10 @@ for r in range(rounds + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            if os.environ.get("AB_EDGES"):
+            if os.environ.get("AB_STEP"):      # the whole step: edges, then match
+                assert lib.sm_find_edges(plan, L.data_ptr(), R.data_ptr(), 0.15, pairs, None, None, None) == 0
+                assert lib.sm_match_wta(plan, pairs, web.data_ptr(), None, None) == 0
+            elif os.environ.get("AB_EDGES"):
                 assert lib.sm_find_edges(plan, L.data_ptr(), R.data_ptr(), 0.15, pairs, None, None, None) == 0
             else:
                 assert lib.sm_match_wta(plan, pairs, web.data_ptr(), None, None) == 0

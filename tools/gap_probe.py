@@ -13,19 +13,28 @@ from stereomatching_amd import pipeline as hip  # noqa: E402
 from stereomatching_amd.capi import check, lib  # noqa: E402
 from stereomatching_amd.synth import CONFIGS, make_pair  # noqa: E402
 
-w, h, d, sw, mode = CONFIGS["C3"]
-left, right = make_pair(w, h, d, seed=1)
-L = torch.from_numpy(left).cuda()[None].contiguous()
-R = torch.from_numpy(right).cuda()[None].contiguous()
-web = torch.empty((1, h, w), dtype=torch.int32, device="cuda")
-plan = hip.StereoPlan(w, h, d, sw, mode)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+w, h, d, sw, mode = CONFIGS[cfg]
+if len(sys.argv) > 3 and sys.argv[3] == "distinct":
+    prs = [make_pair(w, h, d, seed=1 + i) for i in range(P)]
+    import numpy as np
+    L = torch.from_numpy(np.stack([p[0] for p in prs])).cuda().contiguous()
+    R = torch.from_numpy(np.stack([p[1] for p in prs])).cuda().contiguous()
+else:
+    left, right = make_pair(w, h, d, seed=1)
+    L = torch.from_numpy(left).cuda().repeat(P, 1, 1).contiguous()
+    R = torch.from_numpy(right).cuda().repeat(P, 1, 1).contiguous()
+web = torch.empty((P, h, w), dtype=torch.int32, device="cuda")
+plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=P)
+print(plan.describe())
 s = torch.cuda.Stream()
 N = 200
 
 
 def run(n, stream):
     for _ in range(n):
-        check(lib.sm_run(plan._h, C.c_void_p(L.data_ptr()), C.c_void_p(R.data_ptr()), 0.15, 1,
+        check(lib.sm_run(plan._h, C.c_void_p(L.data_ptr()), C.c_void_p(R.data_ptr()), 0.15, P,
                          C.c_void_p(web.data_ptr()), None, C.c_void_p(stream.cuda_stream)))
 
 
@@ -45,6 +54,13 @@ with torch.cuda.stream(s):
     def with_events():
         plan.time_kernels(N); run(N, s)
     timed("stream launches, events around match", with_events)
+    print("   kernel_ms", plan.kernel_ms())
+    # match launches only, back to back
+    def only_match():
+        plan.time_kernels(N)
+        for _ in range(N):
+            check(lib.sm_match_wta(plan._h, P, C.c_void_p(web.data_ptr()), None, C.c_void_p(s.cuda_stream)))
+    timed("match launches only, events", only_match)
     print("   kernel_ms", plan.kernel_ms())
     plan.time_kernels(0)
     g = torch.cuda.CUDAGraph()
