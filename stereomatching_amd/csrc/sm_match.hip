@@ -553,14 +553,17 @@ int sm_match_configure(sm_plan *plan)
         const bool fulld = o.nl * ds == D;
         const void *kfn = bs ? sm_bs_kernel_ptr(o.n, ds, fulld, ghost) : tiled_kernel_ptr(kernel, fulld, ghost);
         const double wps = o.threads / 256.0;            // waves per SIMD per workgroup
-        const double warm = (bs ? 0.35 : 0.4) * (o.n - 1) + 1.0;   // warm-up rows are cheaper than output rows
+        // warm-up rows are cheaper than output rows (no arg-max, no output); the constant is
+        // the per-workgroup overhead (staging, lane set-up) in output-row units.  Refit on
+        // same-device tile-height sweeps (tools/tune_tile_h.py, C2 / C3 / C4 x 8).
+        const double warm = bs ? 0.42 * (o.n - 1) + 1.8 : 0.4 * (o.n - 1) + 1.0;
         // lane-row work relative to ds = 16: the per-row shared views and one more merge level
         const double work = ds == 16 ? 1.0 : 0.5 * 1.10;
         auto lds_of = [&](int th) { return (th + o.n - 1) * rows_words * 4; };
         int th = 0;
         double best_cost = 0;
-        for (int c = 4; c <= 256; c++) {
-            if (c > H && c != 4) break;
+        for (int c = 2; c <= 256; c++) {
+            if (c > H && c != 2) break;
             const int cand = std::min(c, H);
             if (lds_of(cand) > 64 * 1024) break;
             int per_cu = 0;
@@ -572,12 +575,14 @@ int sm_match_configure(sm_plan *plan)
             double cost = 0;
             for (long long left = tiles; left > 0; left -= slots) {
                 const long long m = std::min(left, slots);
-                // the busiest SIMD of this round hosts j waves; measured (PMC): one wave
-                // alone retires an instruction every ~5.5 cycles, two co-resident waves
-                // progress almost as fast each, beyond that they share ~2.5 cycles/instr
+                // the busiest SIMD of this round hosts j waves; measured: one wave alone
+                // retires an instruction every ~5.5 cycles (popcount kernels; ~4.3 for the
+                // bit-sliced kernel), two co-resident waves ~5.5 each, beyond that they
+                // share ~2.5 cycles/instr
                 const long long wg_per_cu = (m + cus - 1) / cus;
                 const int j = std::max(1, (int)std::ceil((double)wg_per_cu * wps - 1e-9));
-                cost += (cand + warm) * work * std::max(5.5, 2.5 * j);
+                const double cpi = bs ? (j <= 1 ? 4.3 : std::max(5.5, 2.5 * j)) : std::max(5.5, 2.5 * j);
+                cost += (cand + warm) * work * cpi;
             }
             if (th == 0 || cost < best_cost * 0.999) { th = cand; best_cost = cost; }
         }
