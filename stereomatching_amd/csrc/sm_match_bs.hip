@@ -143,7 +143,9 @@ __device__ __forceinline__ void addsub_planes(u32 (&s)[SB], const u32 (&hn)[HB],
 template <int CTRL>
 __device__ __forceinline__ u32 dpp(u32 v)
 {
-    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    // every lane of these permutations has a valid source: bound_ctrl with a zero `old`
+    // lets the compiler emit ONE v_mov_b32_dpp (tying `old` to v costs a copy first)
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
 // partner lane of merge step K (lane ^ (1 << K)) for K = 0..3 via DPP, 4/5 via
