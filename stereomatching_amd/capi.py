@@ -57,6 +57,7 @@ _SIGNATURES = {
     "sm_load_edges": (_int, [_vp, _vp, _vp, _int, _vp]),
     "sm_match_wta": (_int, [_vp, _int, _vp, _vp, _vp]),
     "sm_plan_set_pipelined": (_int, [_vp, _int]),
+    "sm_plan_prepare_threshold": (_int, [_vp, C.c_double, _vp]),
     "sm_plan_time_kernels": (_int, [_vp, _int]),
     "sm_plan_time_stride": (_int, [_vp, _int]),
     "sm_plan_kernel_ms": (_int, [_vp, C.POINTER(C.c_double), _intp]),

@@ -862,6 +862,15 @@ extern "C" int sm_debug_edge_table_fast(sm_plan *plan, double threshold, uint8_t
     return SM_OK;
 }
 
+extern "C" int sm_plan_prepare_threshold(sm_plan *plan, double threshold, void *stream)
+{
+    if (!plan) return sm_fail(SM_ERR_ARG, "sm_plan_prepare_threshold: plan is NULL");
+    if (!(threshold >= 0.0 && threshold <= 1.0))
+        return sm_fail(SM_ERR_ARG, "error: threshold must be between 0 and 1");
+    SM_TRY(use_device(plan->device));
+    return ensure_edge_tables(plan, threshold, (hipStream_t)stream);
+}
+
 extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
                              const uint8_t *d_gray_right, double threshold, int pairs,
                              uint8_t *d_edges_left, uint8_t *d_edges_right, void *stream)

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#ifndef NO_WRITES
 static size_t elem_size(ImageType type)
 {
     switch (type) {
@@ -20,6 +21,7 @@ static size_t elem_size(ImageType type)
     default: return 0;
     }
 }
+#endif
 
 void write_gpu_image(void *device_data, int width, int height, int ghost_size, ImageType type,
                      char *filename)

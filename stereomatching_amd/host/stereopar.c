@@ -101,6 +101,9 @@ static void algorithm(const uint8_t *first, const uint8_t *second, int width, in
     int32_t *plane = gpu_alloc(n * sizeof(int32_t));
 #endif
 
+    /* set-up that depends on the parameters only, next to the allocations */
+    GPU(sm_plan_prepare_threshold(plan, params.threshold, NULL));
+
     double t1 = get_time();
 
     /* first step: find edges in both images */

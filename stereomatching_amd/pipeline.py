@@ -76,6 +76,10 @@ class StereoPlan:
         call i).  The inputs given to run() must be complete in memory at call time."""
         check(lib.sm_plan_set_pipelined(self._h, int(enabled)))
 
+    def prepare_threshold(self, threshold: float = DEFAULT_THRESHOLD):
+        """Threshold-only set-up of find_all_edges (it does this itself on first use)."""
+        check(lib.sm_plan_prepare_threshold(self._h, float(threshold), self._stream()))
+
     def time_kernels(self, capacity: int, every: int = 1):
         """Bracket every `every`-th of the coming match launches (at most `capacity` of
         them) with HIP events on the launch stream."""

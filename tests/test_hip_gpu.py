@@ -469,6 +469,8 @@ def test_batched_run_from_gray_images(hip, mode):
         assert np.array_equal(host(web)[i], o["web-1"]), i
         assert np.array_equal(host(best)[i], o["score_best-0"]), i
         assert np.array_equal(host(el)[i], o["edges-1"]) and np.array_equal(host(er)[i], o["edges-2"]), i
+    # (sm_plan_prepare_threshold in advance changes nothing but when the tables are built)
+    plan.prepare_threshold(0.3)
     # a different threshold on the same plan rebuilds the decision tables
     web2, _ = plan.run(dev(left[:1]), dev(right[:1]), 0.05)
     assert np.array_equal(host(web2)[0], oracle.pipeline(pairs[0][0], pairs[0][1], 0.05, d, sw, mode=mode,
