@@ -55,6 +55,7 @@ struct MatchGeom {
     int tiles_x, tiles_y;
     int vec_ok;          // rows are 16-byte aligned -> int4 stores
     int lds_bytes;
+    int cap2;            // bit-sliced kernel: launch the two-waves-per-SIMD variant
 };
 
 struct sm_plan {
@@ -126,7 +127,7 @@ int sm_fail(int code, const char *fmt, ...);
     } while (0)
 
 // sm_match_bs.hip (bit-sliced kernel; nullptr if not built for this window)
-const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost);
+const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost, bool cap2);
 int sm_bs_default_ds(int n);
 int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);
 

@@ -504,7 +504,7 @@ int sm_match_configure(sm_plan *plan)
         g.ext_rows = H + 2 * g.half;
         g.ext_image_words = (long long)g.ext_words * g.ext_rows;
         g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = g.ds = 0;
-        g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = 0;
+        g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = g.cap2 = 0;
         snprintf(plan->describe, sizeof plan->describe,
                  "generic kernel (n=%d, D=%d): 1 lane/pixel, direct window sums", g.n, D);
         return SM_OK;
@@ -551,7 +551,7 @@ int sm_match_configure(sm_plan *plan)
         rows_words_o = rows_words;
         o.tiles_x = ceil_div(W, o.tw);
         const bool fulld = o.nl * ds == D;
-        const void *kfn = bs ? sm_bs_kernel_ptr(o.n, ds, fulld, ghost) : tiled_kernel_ptr(kernel, fulld, ghost);
+        const void *kfn = bs ? sm_bs_kernel_ptr(o.n, ds, fulld, ghost, false) : tiled_kernel_ptr(kernel, fulld, ghost);
         const double wps = o.threads / 256.0;            // waves per SIMD per workgroup
         // warm-up rows are cheaper than output rows (no arg-max, no output); the constant is
         // the per-workgroup overhead (staging, lane set-up) in output-row units.  Refit on
@@ -594,23 +594,29 @@ int sm_match_configure(sm_plan *plan)
         o.nsr = th + o.n - 1;
         o.lds_bytes = o.nsr * rows_words * 4;
         // A grid that fits the chip in one round must also be SPREAD evenly: where the
-        // registers allow more resident workgroups than the round needs (7x7: 12 per CU,
-        // 8 needed) the dispatcher may stack 3 waves on some SIMDs and leave others with
-        // 1, and the launch then lasts as long as the crowded ones (measured at 8 x 1080p:
-        // 100 us spread evenly, 124 us not).  Cap the residency at what the round needs
-        // by asking for a larger LDS allocation than the tile uses: LDS per workgroup in
-        // (160 KB / (cap + 1), 160 KB / cap] admits exactly `cap` workgroups per CU.
+        // registers allow more resident workgroups than the round needs (7x7: 3 waves
+        // per SIMD, 2 needed) the dispatcher may stack 3 waves on some SIMDs and leave
+        // others with 1, and the launch then lasts as long as the crowded ones (measured
+        // at 8 x 1080p: 89 us spread evenly, 117 us not).  Two caps:
+        //  * per SIMD: a grid that fits at two waves per SIMD launches the kernel's
+        //    two-wave variant (k_match_bs<..., CAP2>), where one exists;
+        //  * per CU: an LDS request larger than the tile needs -- LDS per workgroup in
+        //    (160 KB / (cap + 1), 160 KB / cap] admits exactly `cap` workgroups per CU.
+        o.cap2 = 0;
         if (bs) {
             const long long tiles = (long long)o.tiles_x * o.tiles_y * plan->max_pairs;
             const int cap = (int)((tiles + cus - 1) / cus);
+            const void *kcap = sm_bs_kernel_ptr(o.n, ds, fulld, ghost, true);
+            const void *kuse = kfn;
+            if (kcap && cap <= 8 && !getenv("SM_NO_CAP2")) { o.cap2 = 1; kuse = kcap; }
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, o.threads, o.lds_bytes) == hipSuccess
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kuse, o.threads, o.lds_bytes) == hipSuccess
                 && cap >= 2 && cap < per_cu) {
                 const int lds_cu = 160 * 1024, granule = 1280;
                 int want = std::min(64 * 1024, lds_cu / cap / granule * granule);
                 int got = 0;
                 if (want > o.lds_bytes &&
-                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, kfn, o.threads, want) == hipSuccess &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, kuse, o.threads, want) == hipSuccess &&
                     got == cap)
                     o.lds_bytes = want;
             }
@@ -629,7 +635,7 @@ int sm_match_configure(sm_plan *plan)
     if (bs) {
         ds = sm_bs_default_ds(g.n);
         int l2;
-        if ((ds_env == 8 || ds_env == 16) && sm_bs_kernel_ptr(g.n, ds_env, true, ghost) &&
+        if ((ds_env == 8 || ds_env == 16) && sm_bs_kernel_ptr(g.n, ds_env, true, ghost, false) &&
             nl_for(ds_env, l2) <= 32)
             ds = ds_env;
     }
@@ -640,12 +646,12 @@ int sm_match_configure(sm_plan *plan)
 
     snprintf(plan->describe, sizeof plan->describe,
              "%s (n=%d, D=%d, %s): tile %dx%d px, %d threads "
-             "(%d runs x %d shift-lanes of %d), grid %dx%d, LDS %d B/wg, ext %dx%d words",
+             "(%d runs x %d shift-lanes of %d), grid %dx%d, LDS %d B/wg%s, ext %dx%d words",
              bs ? "bit-sliced kernel" : kernel == SM_KERNEL_A ? "tiled kernel A"
                 : kernel == SM_KERNEL_B ? "tiled kernel B" : "tiled kernel C",
              g.n, D, ghost ? "ghost" : "toroidal",
              g.tw, g.tile_h, g.threads, g.runs, g.nl, g.ds, g.tiles_x, g.tiles_y, g.lds_bytes,
-             g.ext_words, g.ext_rows);
+             g.cap2 ? ", 2 waves/SIMD variant" : "", g.ext_words, g.ext_rows);
     return SM_OK;
 }
 

@@ -164,7 +164,15 @@ __device__ __forceinline__ u32 from_partner(u32 v)
 // the kernel
 // ---------------------------------------------------------------------------
 
-template <int N, int DS, bool FULLD, bool GHOST>
+// CAP2: claim a register beyond the 168 a wave may hold when three share a SIMD, so
+// that the hardware admits at most TWO waves of this kernel per SIMD.  For a grid
+// that fits the chip at two waves per SIMD this is what keeps the waves evenly
+// spread: measured (8 x 1080p, 7 x 7, 159 VGPRs), a launch that follows a different
+// kernel finds the SIMDs empty and the dispatcher stacks three waves on some of them
+// while others get one -- 117 us instead of 89; behind a launch of the same kernel
+// the waves inherit the previous, even placement.  A per-CU cap (the LDS request in
+// sm_match_configure) cannot prevent it, a per-SIMD one does.
+template <int N, int DS, bool FULLD, bool GHOST, bool CAP2 = false>
 __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restrict__ ext,
                                                  i32 *__restrict__ web, i32 *__restrict__ best,
                                                  const MatchGeom g)
@@ -179,6 +187,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     static_assert(N + DS - 1 + 31 < 96, "right window must fit three words");
 
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    if (CAP2) asm volatile("" ::: "v175");
     const int tid = threadIdx.x;
     const int pair = blockIdx.z;
     int tile_x, tile_y;
@@ -441,36 +450,45 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
 // host side
 // ---------------------------------------------------------------------------
 
-template <int N, int DS>
-static const void *bs_ptr(bool fulld, bool ghost)
+template <int N, int DS, bool CAP2>
+static const void *bs_ptr4(bool fulld, bool ghost)
 {
-    return fulld ? (ghost ? (const void *)k_match_bs<N, DS, true, true> : (const void *)k_match_bs<N, DS, true, false>)
-                 : (ghost ? (const void *)k_match_bs<N, DS, false, true> : (const void *)k_match_bs<N, DS, false, false>);
+    return fulld ? (ghost ? (const void *)k_match_bs<N, DS, true, true, CAP2> : (const void *)k_match_bs<N, DS, true, false, CAP2>)
+                 : (ghost ? (const void *)k_match_bs<N, DS, false, true, CAP2> : (const void *)k_match_bs<N, DS, false, false, CAP2>);
+}
+// CAPPABLE: this window's kernel needs few enough registers for three waves per SIMD,
+// so a two-wave variant is built next to it
+template <int N, int DS, bool CAPPABLE>
+static const void *bs_ptr(bool fulld, bool ghost, bool cap2)
+{
+    if (cap2) return CAPPABLE ? bs_ptr4<N, DS, CAPPABLE>(fulld, ghost) : nullptr;
+    return bs_ptr4<N, DS, false>(fulld, ghost);
 }
 
 // Built combinations.  16 shifts per lane up to 11 x 11 (the 16 x SB sum planes fit
 // two waves per SIMD); 8 per lane for the larger windows (9 planes per sum) and,
-// for 9 x 9, as a tuning alternative.
-const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost)
+// for 9 x 9, as a tuning alternative.  cap2: the two-waves-per-SIMD variant (nullptr
+// where the kernel is limited to two waves by its registers anyway).
+const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost, bool cap2)
 {
     if (ds == 16) {
         switch (n) {
-        case 3: return bs_ptr<3, 16>(fulld, ghost);
-        case 5: return bs_ptr<5, 16>(fulld, ghost);
-        case 7: return bs_ptr<7, 16>(fulld, ghost);
-        case 9: return bs_ptr<9, 16>(fulld, ghost);
-        case 11: return bs_ptr<11, 16>(fulld, ghost);
+        case 3: return bs_ptr<3, 16, true>(fulld, ghost, cap2);
+        case 5: return bs_ptr<5, 16, true>(fulld, ghost, cap2);
+        case 7: return bs_ptr<7, 16, true>(fulld, ghost, cap2);
+        case 9: return bs_ptr<9, 16, false>(fulld, ghost, cap2);
+        case 11: return bs_ptr<11, 16, false>(fulld, ghost, cap2);
         default: return nullptr;
         }
     }
     if (ds == 8) {
         switch (n) {
-        case 9: return bs_ptr<9, 8>(fulld, ghost);
-        case 13: return bs_ptr<13, 8>(fulld, ghost);
-        case 15: return bs_ptr<15, 8>(fulld, ghost);
-        case 17: return bs_ptr<17, 8>(fulld, ghost);
-        case 19: return bs_ptr<19, 8>(fulld, ghost);
-        case 21: return bs_ptr<21, 8>(fulld, ghost);
+        case 9: return bs_ptr<9, 8, true>(fulld, ghost, cap2);
+        case 13: return bs_ptr<13, 8, true>(fulld, ghost, cap2);
+        case 15: return bs_ptr<15, 8, true>(fulld, ghost, cap2);
+        case 17: return bs_ptr<17, 8, false>(fulld, ghost, cap2);
+        case 19: return bs_ptr<19, 8, false>(fulld, ghost, cap2);
+        case 21: return bs_ptr<21, 8, false>(fulld, ghost, cap2);
         default: return nullptr;
         }
     }
@@ -480,15 +498,15 @@ const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost)
 // shifts per lane the plan should use for this window (0: not built)
 int sm_bs_default_ds(int n)
 {
-    if (sm_bs_kernel_ptr(n, 16, true, false)) return 16;
-    if (sm_bs_kernel_ptr(n, 8, true, false)) return 8;
+    if (sm_bs_kernel_ptr(n, 16, true, false, false)) return 16;
+    if (sm_bs_kernel_ptr(n, 8, true, false, false)) return 8;
     return 0;
 }
 
 int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
 {
     const MatchGeom &g = plan->g;
-    const void *fn = sm_bs_kernel_ptr(g.n, g.ds, g.nl * g.ds == g.D, plan->border == SM_GHOST);
+    const void *fn = sm_bs_kernel_ptr(g.n, g.ds, g.nl * g.ds == g.D, plan->border == SM_GHOST, g.cap2 != 0);
     if (!fn) return sm_fail(SM_ERR_ARG, "bit-sliced kernel not built for n = %d, %d shifts/lane", g.n, g.ds);
     void *args[] = {(void *)&plan->d_ext, (void *)&d_web, (void *)&d_best, (void *)&g};
     hipError_t e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(g.threads), args,

@@ -325,7 +325,7 @@ def env(monkeypatch):
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 @pytest.mark.parametrize("w,h,d,sw", [(300, 150, 128, 9), (71, 53, 30, 5), (130, 70, 64, 7), (90, 61, 64, 11)])
 @pytest.mark.parametrize("variant", [dict(SM_KERNEL="popcount"), dict(SM_DS=8), dict(SM_TILE_H=5),
-                                     dict(SM_DS=8, SM_TILE_H=7)])
+                                     dict(SM_DS=8, SM_TILE_H=7), dict(SM_NO_CAP2=1)])
 def test_alternative_kernels_match_oracle(hip, env, variant, mode, w, h, d, sw):
     """the popcount kernels (general fallback), the 8-shifts-per-lane bit-sliced
     variant and odd tile heights give the same bits as the default path"""
@@ -336,6 +336,10 @@ def test_alternative_kernels_match_oracle(hip, env, variant, mode, w, h, d, sw):
         assert "tiled kernel" in desc
     elif "SM_DS" in variant and sw in (8, 9):       # the 8-per-lane variant is built for 9x9
         assert "lanes of 8" in desc
+    elif "SM_NO_CAP2" in variant:                   # small grids default to the 2-wave variant
+        assert "2 waves/SIMD variant" not in desc
+    elif "SM_TILE_H" in variant and sw in (5, 7) and "SM_DS" not in variant:
+        assert "2 waves/SIMD variant" in desc
     obest, oweb = oracle.hot_path(le, re, d, sw, mode)
     assert np.array_equal(web[0], oweb), desc
     assert np.array_equal(best[0], obest), desc

