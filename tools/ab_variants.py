@@ -47,7 +47,7 @@ for name_, so, envs in entries:
     plan = vp()
     assert lib.sm_plan_create(0, w, h, d, sw, 1 if mode == "ghost" else 0, pairs, C.byref(plan)) == 0
     assert lib.sm_find_edges(plan, L.data_ptr(), R.data_ptr(), 0.15, pairs, None, None, None) == 0
-    libs[name_] = (lib, plan)
+    libs[name_] = (lib, plan, dict(envs))
     for k in envs:
         os.environ.pop(k)
 torch.cuda.synchronize()
@@ -55,7 +55,8 @@ torch.cuda.synchronize()
 ref = None
 times = {k: [] for k in libs}
 for r in range(rounds + 1):
-    for name, (lib, plan) in libs.items():
+    for name, (lib, plan, envs_) in libs.items():
+        os.environ.update(envs_)           # some overrides are read at launch time
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
@@ -73,6 +74,8 @@ for r in range(rounds + 1):
         if os.environ.get("AB_EDGES"):
             assert lib.sm_match_wta(plan, pairs, web.data_ptr(), None, None) == 0
             torch.cuda.synchronize()
+        for k_ in envs_:
+            os.environ.pop(k_)
         if ref is None:
             ref = web.clone()
         else:
