@@ -15,9 +15,16 @@
 #define R1024(x) R4(R256(x))
 #define CLOB "v8", "v9", "v10", "v11", "v16", "v17", "v18", "v19"
 
-template <int BODY, bool VOP2>
+// SKEW: waves enter the loop body at different times (a wave-dependent sleep), so
+// that the waves of a CU fetch DIFFERENT parts of the body at any moment, as the
+// waves of a real kernel do, instead of marching through it in lockstep.
+template <int BODY, bool VOP2, bool SKEW = false>
 __global__ __launch_bounds__(64) void k_body(unsigned *out, int iters)
 {
+    if (SKEW) {
+        const int n = (blockIdx.x * 37) % 61;
+        for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(2);
+    }
     unsigned seed = threadIdx.x * 2654435761u + blockIdx.x;
     asm volatile("v_mov_b32 v8, %0\n v_mov_b32 v9, %0\n v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n"
                  "v_mov_b32 v16, %0\n v_mov_b32 v17, %0\n v_mov_b32 v18, %0\n v_mov_b32 v19, %0\n" :: "v"(seed) : CLOB);
@@ -39,7 +46,7 @@ __global__ __launch_bounds__(64) void k_body(unsigned *out, int iters)
     out[blockIdx.x * 64 + threadIdx.x] = r;
 }
 
-template <int BODY, bool VOP2>
+template <int BODY, bool VOP2, bool SKEW = false>
 static void run(unsigned *out, int waves)
 {
     const int total = 1 << 18;              // instructions per wave
@@ -49,13 +56,13 @@ static void run(unsigned *out, int waves)
     float best = 1e9f;
     for (int rep = 0; rep < 5; rep++) {
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k_body<BODY, VOP2>), dim3(grid), dim3(64), 0, 0, out, iters);
+        hipLaunchKernelGGL((k_body<BODY, VOP2, SKEW>), dim3(grid), dim3(64), 0, 0, out, iters);
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
-    printf("%s body %4d instr (%5d B), %d wave(s)/SIMD: %.3f ns per instruction per SIMD\n", VOP2 ? "v_xor   " : "v_bitop3",
+    printf("%s%s body %4d instr (%5d B), %d wave(s)/SIMD: %.3f ns per instruction per SIMD\n", SKEW ? "skewed " : "", VOP2 ? "v_xor   " : "v_bitop3",
            BODY, BODY * (VOP2 ? 4 : 8), waves, best * 1e6 / ((double)iters * BODY * waves));
 }
 
@@ -66,6 +73,7 @@ int main()
     for (int w = 1; w <= 2; w++) {
         run<64, false>(out, w); run<256, false>(out, w); run<1024, false>(out, w); run<2048, false>(out, w); run<4096, false>(out, w);
         run<64, true>(out, w); run<1024, true>(out, w); run<4096, true>(out, w);
+        run<1024, false, true>(out, w); run<2048, false, true>(out, w); run<4096, false, true>(out, w); run<4096, true, true>(out, w);
     }
     return 0;
 }
