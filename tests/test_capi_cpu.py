@@ -47,6 +47,10 @@ def test_argument_validation_precedes_device_use():
     assert lib.sm_match_wta(None, 1, None, None, None) == capi.SM_ERR_ARG
     assert lib.sm_find_edges(None, None, None, 0.15, 1, None, None, None) == capi.SM_ERR_ARG
     assert b"plan is NULL" in lib.sm_last_error()
+    assert lib.sm_plan_prepare_threshold(None, 0.15, None) == capi.SM_ERR_ARG
+    assert lib.sm_plan_time_stride(None, 8) == capi.SM_ERR_ARG
+    assert lib.sm_plan_time_kernels(None, 4) == capi.SM_ERR_ARG
+    assert lib.sm_plan_set_pipelined(None, 1) == capi.SM_ERR_ARG
     assert lib.sm_plan_describe(None) == b""
     lib.sm_plan_destroy(None)  # no-op
 
