@@ -36,8 +36,8 @@ extern "C" const char *sm_last_error(void) { return g_err; }
 // 128.0 is 32768).  A three-term sum of such values is exact in double, so
 // (a+b+c)/3.0 == sum/768.0 with a single rounding, and every later operation
 // is one IEEE operation exactly as in the C source.  Built with
-// -ffp-contract=off; tests/test_edges.py checks all 766*766 in-image sum
-// pairs against the host's arithmetic.
+// -ffp-contract=off; tests/test_hip_gpu.py (test_edge_decision_exhaustive) checks
+// all 766*766 in-image sum pairs against the host's arithmetic.
 __device__ __forceinline__ bool contrast_test(int sa, int sb, double threshold)
 {
     const double ma = (double)sa / 768.0;
