@@ -11,15 +11,24 @@ reference's timed region (stages only, inputs resident, no file writes:
 /root/reference/src/stereo.cu:308,:334) up to `web`.
 
 Metric (BASELINE.json): Mpixel-disparities/s = W*H*D*pairs / t / 1e6, whole
-job over all ranks.  N > 1: one process per GPU (torchrun), every rank runs
-the same number of its own pairs (weak scaling), no data-path collective;
-barrier + device sync on both sides of the timed region, max over ranks.
+job over all ranks.
+
+N > 1: one process per GPU, every rank runs the same number of its own pairs
+(weak scaling), no data-path collective; barrier + device sync on both sides
+of the timed region, max over ranks.  Started either by torchrun (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment) or by `python bench.py --gpus N`
+alone: the parent then starts the N ranks as CHILD processes before it has
+touched torch or the GPU, relays rank 0's JSON line and exits with the worst
+return code.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the dominant kernel (k_match_wta) against the HBM roof, on the
-                materialised-cost-volume byte model A_cv; the
-                compulsory-traffic model A_min is printed next to it because a
-                fused kernel moves almost no bytes
+  roofline      the dominant kernel (k_match_bs) against the roof that binds
+                it: integer VALU issue.  frac = VALU wave-instructions of one
+                launch / measured launch time / (1024 SIMDs x 2.4 GHz / 2 cycles
+                per wave64 instruction).  The byte models of SURVEY.md 8d are
+                printed as named extras: hbm_frac_min (compulsory bytes) and
+                throughput_bar_frac (the materialised-cost-volume model A_cv, a
+                throughput bar, NOT traffic: the fused kernel never moves it).
   cpu_baseline  the oracle's structure-faithful C port timed on this host's
                 cores on a bounded band of the same workload (rank 0, N = 1)
 """
@@ -28,6 +37,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,11 +46,14 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz max clock, a wave64 VALU
+# instruction issues over 2 cycles -> wave-instructions per second, whole chip
+VALU_PEAK_GIPS = 256 * 4 * 2.4 / 2.0 * 1.0      # = 1228.8 G wave-instr/s
 A_CV_BYTES = 10.0               # per pixel-disparity
 A_MIN_BYTES = 6.0               # per pixel          
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -56,13 +69,57 @@ def parse():
                          "(sm_plan_set_pipelined; measured: no net gain, both kernels are VALU-heavy)")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region, collect the maps on rank 0 over RCCL and time it")
-    return ap.parse_args()
+    ap.add_argument("--e2e", action="store_true",
+                    help="also measure the PCIe-inclusive rate through the C ABI alone (pinned "
+                         "buffers, async copies) and report it as an extra `e2e` object")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------
+# N > 1 without torchrun: start the ranks as children.  Nothing in this function
+# (or before it in main) imports torch or touches the GPU.
+# ---------------------------------------------------------------------------
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        # rank 0's stdout is the JSON line; every other rank's goes to our stderr
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        sys.stdout.write(out0.decode())
+        sys.stdout.flush()
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    except BaseException:
+        rc = rc or 1
+        raise
+    finally:
+        for p in procs:                 # exact PIDs we started, never a pattern
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def cpu_baseline(w, d, sw, mode, rows, threshold):
     """Time the oracle's faithful port (same loop nest and modulo indexing as
     stereo.c) on a full-width band of `rows` rows of the workload."""
-    import numpy as np
     from stereomatching_amd.synth import make_pair
     from tests import oracle    # checker: the only place bench.py touches oracle/
 
@@ -101,28 +158,40 @@ def cpu_baseline(w, d, sw, mode, rows, threshold):
     return out
 
 
+def timing_stride(steps: int) -> int:
+    """Bracket every `stride`-th match launch with HIP events: an event record costs
+    ~4 us on the launch stream (tools/gap_probe.py), so long runs sample every 8th
+    launch; short runs sample densely enough for >= 10 timed launches."""
+    return max(1, min(8, steps // 10))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    # plumbing rehearsals (never set by the driver):
+    #   SM_BENCH_REHEARSAL=1  N ranks on device 0 over gloo (a 1-GPU box), real kernels
+    #   SM_BENCH_DRYRUN=1     no GPU at all: the step is a sleep; exercises launcher,
+    #                         rendezvous, barrier, max-over-ranks and the JSON line on CPU.
+    #                         Its line says so and carries value 0.
+    dryrun = os.environ.get("SM_BENCH_DRYRUN") == "1"
+    rehearsal = dryrun or os.environ.get("SM_BENCH_REHEARSAL") == "1"
+
     import torch
     from stereomatching_amd import shard
     from stereomatching_amd.synth import CONFIGS, make_pair
 
-    # rehearsal hooks for a 1-GPU box (never set by the driver): run N ranks on
-    # device 0 with the gloo backend to exercise the multi-process path
-    rehearsal = os.environ.get("SM_BENCH_REHEARSAL") == "1"
     rank, local_rank, world = shard.init("gloo" if rehearsal else None)
     if rehearsal:
         local_rank = 0
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torchrun",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as "
+                  f"`python bench.py --gpus {args.gpus}` or under torchrun with "
+                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    from stereomatching_amd import pipeline   # fails loudly if the HIP library is missing
+    red_dev = "cpu" if rehearsal else None
 
     # rank 0's job description goes to every rank (RCCL broadcast; a no-op at N = 1)
     job = shard.broadcast_params(dict(config=args.config, pairs=args.pairs, threshold=args.threshold,
@@ -131,6 +200,37 @@ def main():
     args.steps, args.warmup = job["steps"], job["warmup"]
     w, h, d, sw, mode = CONFIGS[args.config]
     pairs = args.pairs
+
+    if dryrun:
+        for _ in range(args.warmup):
+            time.sleep(0.0005)
+        shard.barrier()
+        shard.max_over_ranks(0.0, "cpu")
+        shard.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.0005)
+        shard.barrier()
+        elapsed = shard.max_over_ranks(time.perf_counter() - t0, "cpu")
+        if rank == 0:
+            print(json.dumps({"metric": "Mpixel-disparities/s", "value": 0.0,
+                              "unit": "Mpixel-disparities/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dry_run": True, "data": "none: SM_BENCH_DRYRUN plumbing rehearsal, no GPU work",
+                              "config": {"workload": f"{args.config} x {pairs} pair(s)/rank (not run)"}}),
+                  flush=True)
+        shard.finalize()
+        return
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if red_dev is None:
+        red_dev = dev
+
+    from stereomatching_amd import pipeline   # fails loudly if the HIP library is missing
+
     plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs, device=local_rank)
 
     import numpy as np
@@ -155,6 +255,7 @@ def main():
     # (edge kernel of step i+1 beside the match kernel of step i on the plan's internal
     # stream).  Every step still does all its work.
     plan.set_pipelined(args.pipeline)
+    plan.prepare_threshold(args.threshold)     # set-up next to the allocations
 
     def step():
         check(lib.sm_run(plan._h, p_l, p_r, args.threshold, pairs, p_web, p_best, stream))
@@ -164,21 +265,21 @@ def main():
     torch.cuda.synchronize(dev)
     # communicator start-up (RCCL) belongs to the warm-up, not to the timed region
     shard.barrier()
-    shard.max_over_ranks(0.0, "cpu" if rehearsal else dev)
+    shard.max_over_ranks(0.0, red_dev)
     # HIP events around the dominant kernel, recorded by the library on the stream
-    # the kernel is launched on, inside the timed region itself.  Event records cost
-    # ~4 us each on that stream (tools/gap_probe.py), so every 8th launch is bracketed.
-    every = 8 if args.steps >= 16 else 1
+    # the kernel is launched on, inside the timed region itself
+    every = timing_stride(args.steps)
     n_samples = (args.steps + every - 1) // every
     plan.time_kernels(n_samples, every)
 
     shard.barrier()
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
     shard.barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, "cpu" if rehearsal else dev)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, red_dev)
 
     kernel_ms, n_timed = plan.kernel_ms()
     assert n_timed == n_samples
@@ -192,28 +293,58 @@ def main():
         g0 = time.perf_counter()
         shard.gather_maps(web.cpu() if rehearsal else web, pairs * world, rank, world)
         torch.cuda.synchronize(dev)
-        gather_ms = shard.max_over_ranks(time.perf_counter() - g0, "cpu" if rehearsal else dev) * 1e3
+        gather_ms = shard.max_over_ranks(time.perf_counter() - g0, red_dev) * 1e3
 
     if rank != 0:
+        shard.finalize()
         return
 
-    acv = A_CV_BYTES * units_per_step / (kernel_ms * 1e-3) / 1e9   # GB/s
-    amin_kernel = (4.0 * w * h * pairs + plan.workspace_bytes() / 2 / plan.max_pairs * pairs) \
-        / (kernel_ms * 1e-3) / 1e9
+    kernel_s = kernel_ms * 1e-3
+    acv = A_CV_BYTES * units_per_step / kernel_s / 1e9             # GB/s (throughput bar)
+    compulsory = 4.0 * w * h * pairs + plan.workspace_bytes() / 2 / plan.max_pairs * pairs
+    amin_kernel = compulsory / kernel_s / 1e9
     amin_step = A_MIN_BYTES * w * h * pairs / (elapsed / args.steps) / 1e9
-    # HBM bytes and VALU instruction count of one launch come from separate rocprofv3
-    # --pmc passes of this same command (tools/collect_profiles.sh), committed under
-    # profiles/; null if no profile exists for this configuration
-    traffic = valu_issue = None
+    # VALU wave-instructions of one launch: the plan's analytic model (per-wave set-up +
+    # warm-up rows + output rows, coefficients fitted to SQ_INSTS_VALU of rocprofv3 --pmc
+    # passes at several tile heights: stereomatching_amd/valu_counts.json)
+    model = plan.valu_model(pairs, want_best=args.with_best)
+    # HBM bytes of one launch: separate rocprofv3 --pmc passes of this same command
+    # (tools/collect_profiles.sh), committed under profiles/; null if none for this config
+    traffic = traffic_src = None
     tfile = ROOT / "profiles" / "hbm_traffic.json"
     if tfile.exists():
         t = json.loads(tfile.read_text()).get(f"{args.config}:{pairs}")
         if t:
             traffic = t["bytes_per_launch"]
-            if t.get("valu_wave_instructions_per_launch"):
-                # fraction of the chip's full-rate VALU issue (1024 SIMDs x one wave64
-                # instruction per ~1.0 ns) this launch sustained
-                valu_issue = t["valu_wave_instructions_per_launch"] / (kernel_ms * 1e-3) / (1024 * 1.0e9)
+            traffic_src = t.get("source", "profiles/hbm_traffic.json")
+
+    roof = {
+        "bound": "valu",
+        "kernel": "k_match_bs" if "bit-sliced" in plan.describe() else "k_match_wta",
+        "achieved": None, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s", "frac": None,
+        "peak_definition": "1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction "
+                           "(MI355X_MICROARCH.md)",
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "kernel_ms": round(kernel_ms, 4),
+        "kernel_launches_timed": n_timed,
+    }
+    if model:
+        ach = model["wave_instructions"] / kernel_s / 1e9
+        roof.update(achieved=round(ach, 1), frac=round(ach / VALU_PEAK_GIPS, 4),
+                    valu_wave_instructions_per_launch=model["wave_instructions"],
+                    valu_model=model["model"], valu_model_source=model["source"])
+    roof.update({
+        "hbm_frac_min": round(amin_kernel / HBM_PEAK_GBPS, 5),
+        "hbm_achieved_min_GBps": round(amin_kernel, 1),
+        "hbm_model_min": "compulsory bytes of this launch (packed edge bits in + i32 web out) / "
+                         "kernel time / 8 TB/s",
+        "throughput_bar_frac": round(acv / HBM_PEAK_GBPS, 4),
+        "throughput_bar_model": "A_cv = 10 B per pixel-disparity (materialised cost volume, SURVEY 8d) "
+                                "/ kernel time / 8 TB/s: a throughput bar (>= 0.6 <=> the north-star "
+                                "target), NOT traffic -- the fused kernel never moves these bytes",
+        "step_min_GBps": round(amin_step, 1),
+    })
 
     out = {
         "metric": "Mpixel-disparities/s",
@@ -235,30 +366,19 @@ def main():
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
             "pipelined": args.pipeline,
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "k_match_bs" if "bit-sliced" in plan.describe() else "k_match_wta",
-            "achieved": round(acv, 1),
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": round(acv / HBM_PEAK_GBPS, 4),
-            "traffic": traffic,
-            "kernel_ms": round(kernel_ms, 4),
-            "kernel_launches_timed": n_timed,
-            "model": "A_cv = 10 B per pixel-disparity (materialised cost volume, SURVEY 8d); "
-                     "the fused kernel never moves these bytes, so frac > 1 is possible",
-            "achieved_min": round(amin_kernel, 1),
-            "frac_min": round(amin_kernel / HBM_PEAK_GBPS, 5),
-            "model_min": "compulsory bytes of this launch: packed edge bits in + i32 web out",
-            "step_min_GBps": round(amin_step, 1),
-            "valu_issue_frac": round(valu_issue, 3) if valu_issue else None,
-        },
+        "roofline": roof,
     }
+    if rehearsal:
+        out["rehearsal"] = "SM_BENCH_REHEARSAL: all ranks on device 0 over gloo"
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
+    if args.e2e and world == 1:
+        from tools import e2e_bench
+        out["e2e"] = e2e_bench.measure(args.config, local_rank)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, d, sw, mode, args.cpu_rows, args.threshold)
     print(json.dumps(out), flush=True)
+    shard.finalize()
 
 
 if __name__ == "__main__":

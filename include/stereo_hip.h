@@ -87,6 +87,22 @@ void sm_plan_destroy(sm_plan *plan);
 /* human-readable description of the kernel variant and tiling the plan
  * selected (for logs / bench.py); the string lives as long as the plan */
 const char *sm_plan_describe(const sm_plan *plan);
+/* the geometry the plan selected (kernel variant, tiling, packed-image extents):
+ * what analytic cost models and tests need; plain ints only */
+typedef struct sm_geometry {
+    int kernel;            /* 0..2 popcount kernels A/B/C, 3 generic, 4 bit-sliced */
+    int window;            /* n = 2*(square_width/2)+1 */
+    int shifts_per_lane;   /* shifts one lane carries */
+    int shift_lanes;       /* lanes that split one pixel group's shift range */
+    int threads;           /* per workgroup */
+    int tile_w, tile_h;    /* output pixels per workgroup */
+    int tiles_x, tiles_y;  /* grid (x pairs in z) */
+    int ext_words, ext_rows, pad_l;   /* packed edge image: u32 words per row, rows, left pad px */
+    int lds_bytes;         /* dynamic LDS request per workgroup */
+    int two_wave_variant;  /* bit-sliced kernel capped at two waves per SIMD */
+    int edge_rows_per_wave;/* packed-image rows one wave of the edge kernel produces */
+} sm_geometry;
+int sm_plan_geometry(const sm_plan *plan, sm_geometry *out);
 /* bytes of private device workspace */
 size_t sm_plan_workspace_bytes(const sm_plan *plan);
 
@@ -132,7 +148,9 @@ int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d_best,
  * PREVIOUS call; the match kernel itself still goes to `stream`, and
  * synchronising `stream` still means "all results are there".  The caller
  * promises that the input images handed to sm_run are complete in memory when
- * sm_run is called (it no longer orders them behind earlier work on `stream`).
+ * sm_run is called (it no longer orders them behind earlier work on `stream`);
+ * enabled = 2 keeps that ordering too (one more event per call): use it when the
+ * inputs are uploaded asynchronously on `stream` just before sm_run.
  * Off by default.                                                             */
 int sm_plan_set_pipelined(sm_plan *plan, int enabled);
 

@@ -35,6 +35,14 @@ def declared_symbols() -> list[str]:
 _vp, _int, _sz, _dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_double
 _intp = C.POINTER(C.c_int)
 
+class Geometry(C.Structure):
+    """sm_geometry of include/stereo_hip.h"""
+    _fields_ = [(n, C.c_int) for n in (
+        "kernel", "window", "shifts_per_lane", "shift_lanes", "threads", "tile_w", "tile_h",
+        "tiles_x", "tiles_y", "ext_words", "ext_rows", "pad_l", "lds_bytes", "two_wave_variant",
+        "edge_rows_per_wave")]
+
+
 _SIGNATURES = {
     "sm_last_error": (C.c_char_p, []),
     "sm_device_count": (_int, [_intp]),
@@ -53,6 +61,7 @@ _SIGNATURES = {
     "sm_plan_destroy": (None, [_vp]),
     "sm_plan_describe": (C.c_char_p, [_vp]),
     "sm_plan_workspace_bytes": (_sz, [_vp]),
+    "sm_plan_geometry": (_int, [_vp, C.POINTER(Geometry)]),
     "sm_find_edges": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp]),
     "sm_load_edges": (_int, [_vp, _vp, _vp, _int, _vp]),
     "sm_match_wta": (_int, [_vp, _int, _vp, _vp, _vp]),

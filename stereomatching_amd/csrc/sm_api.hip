@@ -359,6 +359,9 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
         const int over = g.ext_words * 32 - g.pad_l - g.w;     // uniform: columns right of the image
         if (g.w >= g.pad_l && g.w >= over) xq = x < 0 ? x + g.w : (x >= g.w ? x - g.w : x);
         else                               xq = pos_mod(x, g.w);
+        // lanes of the grid's round-up beyond the ext image load nothing meaningful, but
+        // they do load: keep their addresses inside the row (one wrap is not enough there)
+        if (!in_ext) xq = 0;
         xn = lane == 63 ? (xq + 4 == g.w ? 0 : xq + 4) : (xq == 0 ? g.w - 1 : xq - 1);
         vq = vl = vr = true;
     }
@@ -740,6 +743,7 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_free[b], hipEventDisableTiming);
     }
     p->d_ext = p->d_ext_buf[0];
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_inputs, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flags, 4 * sizeof(i32));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_edge_tab, 768 * sizeof(u32));
     if (e == hipSuccess) e = hipMemset(p->d_ext, 0, p->ext_bytes);
@@ -751,6 +755,7 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
             if (p->ev_free[b]) (void)hipEventDestroy(p->ev_free[b]);
         }
         if (p->edge_stream) (void)hipStreamDestroy(p->edge_stream);
+        if (p->ev_inputs) (void)hipEventDestroy(p->ev_inputs);
         if (p->d_flags) (void)hipFree(p->d_flags);
         if (p->d_edge_tab) (void)hipFree(p->d_edge_tab);
         free(p);
@@ -787,12 +792,35 @@ extern "C" void sm_plan_destroy(sm_plan *plan)
         (void)hipEventDestroy(plan->ev_free[b]);
     }
     (void)hipStreamDestroy(plan->edge_stream);
+    (void)hipEventDestroy(plan->ev_inputs);
     (void)hipFree(plan->d_flags);
     (void)hipFree(plan->d_edge_tab);
     free(plan);
 }
 
 extern "C" const char *sm_plan_describe(const sm_plan *plan) { return plan ? plan->describe : ""; }
+
+extern "C" int sm_plan_geometry(const sm_plan *plan, sm_geometry *out)
+{
+    if (!plan || !out) return sm_fail(SM_ERR_ARG, "sm_plan_geometry: NULL argument");
+    const MatchGeom &g = plan->g;
+    out->kernel = plan->kernel;
+    out->window = g.n;
+    out->shifts_per_lane = g.ds;
+    out->shift_lanes = g.nl;
+    out->threads = g.threads;
+    out->tile_w = g.tw;
+    out->tile_h = g.tile_h;
+    out->tiles_x = g.tiles_x;
+    out->tiles_y = g.tiles_y;
+    out->ext_words = g.ext_words;
+    out->ext_rows = g.ext_rows;
+    out->pad_l = g.pad_l;
+    out->lds_bytes = g.lds_bytes;
+    out->two_wave_variant = g.cap2;
+    out->edge_rows_per_wave = (g.w % 4 == 0) ? SM_EDGE4_ROWS : SM_EDGE_ROWS;
+    return SM_OK;
+}
 
 extern "C" size_t sm_plan_workspace_bytes(const sm_plan *plan)
 {
@@ -887,7 +915,11 @@ extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
     const dim3 grid((g.ext_words * 32 + 255) / 256, (g.ext_rows + SM_EDGE_ROWS - 1) / SM_EDGE_ROWS,
                     pairs * 2), block(256);
     const bool ghost = plan->border == SM_GHOST;
-    if (g.w % 4 == 0 && !getenv("SM_EDGES1")) {
+    // the 4-pixels-per-lane kernel moves dwords: rows (w % 4 == 0) and base pointers
+    // must be 4-byte aligned, else the any-width kernel takes over
+    const bool aligned4 = (((uintptr_t)d_gray_left | (uintptr_t)d_gray_right |
+                            (uintptr_t)d_edges_left | (uintptr_t)d_edges_right) & 3) == 0;
+    if (g.w % 4 == 0 && aligned4 && !getenv("SM_EDGES1")) {
         const dim3 grid4((g.ext_words * 8 + 255) / 256, (g.ext_rows + SM_EDGE4_ROWS - 1) / SM_EDGE4_ROWS,
                          pairs * 2);
 #define SM_EDGES_GO(G, T)                                                                      \
@@ -935,7 +967,15 @@ extern "C" int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d
     const bool timed = plan->timing_n < plan->timing_cap &&
                        plan->timing_seen++ % plan->timing_every == 0;
     if (timed) SM_HIP(hipEventRecord(plan->t_begin[plan->timing_n], (hipStream_t)stream));
-    SM_TRY(sm_match_launch(plan, pairs, d_web, d_best, (hipStream_t)stream));
+    {
+        // int4 stores need 16-byte aligned maps; otherwise this launch stores scalars
+        // (kernel arguments are copied at launch time)
+        const int vec_ok = plan->g.vec_ok;
+        if ((((uintptr_t)d_web | (uintptr_t)d_best) & 15) != 0) plan->g.vec_ok = 0;
+        const int rc = sm_match_launch(plan, pairs, d_web, d_best, (hipStream_t)stream);
+        plan->g.vec_ok = vec_ok;
+        if (rc) return rc;
+    }
     if (timed) SM_HIP(hipEventRecord(plan->t_end[plan->timing_n++], (hipStream_t)stream));
     if (plan->pipelined) {
         // the next-but-one sm_run must not overwrite this buffer before the launch has read it
@@ -1007,7 +1047,7 @@ extern "C" int sm_plan_kernel_ms(sm_plan *plan, double *mean_ms, int *launches)
 extern "C" int sm_plan_set_pipelined(sm_plan *plan, int enabled)
 {
     if (!plan) return sm_fail(SM_ERR_ARG, "sm_plan_set_pipelined: plan is NULL");
-    plan->pipelined = enabled != 0;
+    plan->pipelined = enabled == 2 ? 2 : (enabled != 0);
     return SM_OK;
 }
 
@@ -1030,6 +1070,12 @@ extern "C" int sm_run(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *
         plan->unfenced = 0;
     }
     if (plan->ev_free_set[b]) SM_HIP(hipStreamWaitEvent(plan->edge_stream, plan->ev_free[b], 0));
+    if (plan->pipelined == 2) {
+        // ordered mode: the inputs may have been produced by earlier work on `stream`
+        // (an asynchronous upload, say); the edge kernel waits for it
+        SM_HIP(hipEventRecord(plan->ev_inputs, (hipStream_t)stream));
+        SM_HIP(hipStreamWaitEvent(plan->edge_stream, plan->ev_inputs, 0));
+    }
     plan->cur = b;
     plan->d_ext = plan->d_ext_buf[b];
     SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr,

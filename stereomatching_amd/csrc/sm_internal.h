@@ -67,10 +67,11 @@ struct sm_plan {
     u32 *d_ext_buf[2];   // double buffer, so that sm_run can pipeline consecutive calls
     size_t ext_bytes;    // of one buffer
     int cur;             // index of d_ext in d_ext_buf
-    int pipelined;       // sm_plan_set_pipelined
+    int pipelined;       // sm_plan_set_pipelined: 0 off, 1 on, 2 on + inputs ordered behind `stream`
     hipStream_t edge_stream;     // internal: edge detection of call i+1 beside the match of call i
     hipEvent_t ev_edges[2];      // edges written into buffer b
     hipEvent_t ev_free[2];       // last match reading buffer b has finished
+    hipEvent_t ev_inputs;        // pipelined == 2: the caller's stream up to this sm_run
     int ev_free_set[2];
     int unfenced;                // match launches went out without a release event
     // optional timing of the match launches (sm_plan_time_kernels)

@@ -68,12 +68,26 @@ class StereoPlan:
     def describe(self) -> str:
         return lib.sm_plan_describe(self._h).decode()
 
+    def geometry(self) -> dict:
+        """The kernel variant and tiling the plan selected (sm_plan_geometry)."""
+        g = capi.Geometry()
+        check(lib.sm_plan_geometry(self._h, C.byref(g)))
+        return {n: getattr(g, n) for n, _ in capi.Geometry._fields_}
+
+    def valu_model(self, pairs: int = 1, want_best: bool = False):
+        """VALU wave-instructions of one match launch from the analytic model of
+        valu_model.py; None where no coefficients exist for this kernel variant."""
+        from . import valu_model
+        return valu_model.match_launch(self.geometry(), self.width, self.height, self.num_shifts,
+                                       self.border, pairs, want_best)
+
     def workspace_bytes(self) -> int:
         return int(lib.sm_plan_workspace_bytes(self._h))
 
     def set_pipelined(self, enabled: bool = True):
         """Let consecutive run() calls overlap (edges of call i+1 beside the match of
-        call i).  The inputs given to run() must be complete in memory at call time."""
+        call i).  With True the inputs given to run() must be complete in memory at call
+        time; with 2 they may still be in flight on the current stream."""
         check(lib.sm_plan_set_pipelined(self._h, int(enabled)))
 
     def prepare_threshold(self, threshold: float = DEFAULT_THRESHOLD):
@@ -105,6 +119,16 @@ class StereoPlan:
             raise ValueError(f"{name}: shape {tuple(t.shape)} is not (pairs, {self.height}, {self.width})")
         return t
 
+    def _out(self, t, pairs, name):
+        """A caller-supplied result buffer gets the same checks as an input (a wrong
+        buffer would otherwise become an out-of-bounds device write)."""
+        if t is None:
+            return self._new(pairs, torch.int32)
+        t = self._images(t, torch.int32, name)
+        if t.shape[0] < pairs:
+            raise ValueError(f"{name}: room for {t.shape[0]} maps, {pairs} pairs requested")
+        return t
+
     def _new(self, pairs, dtype):
         return torch.empty((pairs, self.height, self.width), dtype=dtype, device=self._dev)
 
@@ -132,9 +156,8 @@ class StereoPlan:
     def match_wta(self, pairs=1, want_best=True, web=None, best=None):
         """fillup_matches + fillup_scores + find_highest_scoring_shifts
         (src/stereo.cu:127-225) in one launch -> (web, best)."""
-        web = self._new(pairs, torch.int32) if web is None else web
-        if want_best and best is None:
-            best = self._new(pairs, torch.int32)
+        web = self._out(web, pairs, "web")
+        best = self._out(best, pairs, "best") if want_best else None
         check(lib.sm_match_wta(self._h, pairs, _ptr(web), _ptr(best if want_best else None),
                                self._stream()))
         return web, (best if want_best else None)
@@ -144,9 +167,8 @@ class StereoPlan:
         left = self._images(left, torch.uint8, "left")
         right = self._images(right, torch.uint8, "right")
         pairs = left.shape[0]
-        web = self._new(pairs, torch.int32) if web is None else web
-        if want_best and best is None:
-            best = self._new(pairs, torch.int32)
+        web = self._out(web, pairs, "web")
+        best = self._out(best, pairs, "best") if want_best else None
         check(lib.sm_run(self._h, _ptr(left), _ptr(right), float(threshold), pairs, _ptr(web),
                          _ptr(best if want_best else None), self._stream()))
         return web, (best if want_best else None)

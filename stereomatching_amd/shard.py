@@ -3,8 +3,8 @@
 Stereo pairs are independent, so the hot path shards with NO data-path
 collective: pair j belongs to rank j mod world.  torch.distributed (backend
 "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests) is used only for
-the barrier / max-over-ranks of the timing contract and, optionally, to
-collect the result maps on rank 0.
+the barrier / max-over-ranks of the timing contract, the broadcast of rank 0's
+job description and, optionally, to collect the result maps on rank 0.
 """
 from __future__ import annotations
 
@@ -64,22 +64,37 @@ def max_over_ranks(seconds: float, device="cpu") -> float:
 
 
 def gather_maps(local: torch.Tensor, total_pairs: int, rank: int, world: int):
-    """Collect every rank's (pairs_r, H, W) int32 maps on rank 0 in pair order.
-    Ranks may hold different counts (total_pairs % world != 0), so the exchange is
-    an all_gather of equally padded blocks; returns (total_pairs, H, W) on rank 0,
-    None elsewhere."""
+    """Collect every rank's (pairs_r, H, W) maps on rank 0 in pair order: each rank
+    r > 0 sends exactly its own maps to rank 0 (point-to-point over RCCL / xGMI, all
+    transfers in flight together); nobody else receives anything.  Ranks may hold
+    different counts (total_pairs % world != 0).  Returns (total_pairs, H, W) on rank
+    0, None elsewhere."""
     if world == 1:
         return local
-    per = (total_pairs + world - 1) // world
-    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    blocks = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(blocks, pad)
+    shape = tuple(local.shape[1:])
+    counts = [len(pairs_for_rank(total_pairs, r, world)) for r in range(world)]
+    if local.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} maps, its share is {counts[rank]}")
     if rank != 0:
+        if counts[rank]:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), 0)]):
+                req.wait()
         return None
-    out = torch.empty((total_pairs,) + tuple(local.shape[1:]), dtype=local.dtype,
-                      device=local.device)
-    for r in range(world):
-        idx = pairs_for_rank(total_pairs, r, world)
-        out[idx] = blocks[r][: len(idx)]
+    blocks = {0: local}
+    ops = []
+    for r in range(1, world):
+        if counts[r]:
+            blocks[r] = torch.empty((counts[r],) + shape, dtype=local.dtype, device=local.device)
+            ops.append(dist.P2POp(dist.irecv, blocks[r], r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    out = torch.empty((total_pairs,) + shape, dtype=local.dtype, device=local.device)
+    for r, blk in blocks.items():
+        out[pairs_for_rank(total_pairs, r, world)] = blk
     return out
+
+
+def finalize():
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -1,0 +1,60 @@
+"""Analytic VALU instruction count of one match launch.
+
+The bit-sliced kernel (csrc/sm_match_bs.hip) runs one wave per workgroup, and
+every wave executes the same straight-line code per row: a fixed set-up
+(staging, lane roles, the N warm-up rows of its tile) and then one loop
+iteration per output row (sliding update of all sums, arg-max over the lane's
+shifts, merge across the shift lanes, planes -> integers).  So
+
+    wave-instructions(launch) = waves * A  +  B * sum over waves of rows_out
+                              = tiles_x * tiles_y * pairs * A + B * tiles_x * H * pairs
+
+with two coefficients per kernel variant.  They are FITTED to SQ_INSTS_VALU of
+separate `rocprofv3 --pmc` passes at several tile heights
+(tools/fit_valu_model.py on the GPU box -> valu_counts.json next to this file;
+the raw counter values are kept under profiles/); the residual of the fit is
+stored with them.  bench.py divides this count by the measured launch time to
+get the achieved VALU issue rate of its roofline object.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+COUNTS = Path(__file__).resolve().parent / "valu_counts.json"
+
+
+def variant_key(geom: dict, num_shifts: int, border: int, want_best: bool) -> str:
+    fulld = geom["shift_lanes"] * geom["shifts_per_lane"] == num_shifts
+    return (f"k{geom['kernel']}:n{geom['window']}:ds{geom['shifts_per_lane']}:nl{geom['shift_lanes']}:"
+            f"{'ghost' if border else 'toroidal'}:fulld{int(fulld)}:best{int(bool(want_best))}")
+
+
+def waves_and_rows(geom: dict, height: int, pairs: int):
+    """(waves of the launch, sum over waves of the output rows each produces)."""
+    waves_per_wg = max(1, geom["threads"] // 64)
+    waves = geom["tiles_x"] * geom["tiles_y"] * pairs * waves_per_wg
+    rows = geom["tiles_x"] * height * pairs * waves_per_wg
+    return waves, rows
+
+
+def match_launch(geom: dict, width: int, height: int, num_shifts: int, border: int,
+                 pairs: int, want_best: bool = False):
+    if not COUNTS.exists():
+        return None
+    table = json.loads(COUNTS.read_text())
+    key = variant_key(geom, num_shifts, border, want_best)
+    c = table.get("variants", {}).get(key)
+    if not c:
+        return None
+    waves, rows = waves_and_rows(geom, height, pairs)
+    total = c["per_wave"] * waves + c["per_wave_row"] * rows
+    return {
+        "wave_instructions": int(round(total)),
+        "model": f"{waves} waves x {c['per_wave']:.0f} (set-up + {geom['window']} warm-up rows) + "
+                 f"{rows} wave-rows x {c['per_wave_row']:.0f}",
+        "source": f"{table.get('source', 'valu_counts.json')}; fit residual <= "
+                  f"{c.get('max_rel_residual', 0) * 100:.2f} % over tile heights "
+                  f"{[p[0] for p in c.get('fit_points', [])]}",
+        "variant": key,
+    }

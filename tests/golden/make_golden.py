@@ -37,13 +37,36 @@ CASES = {
 }
 PLANE_SHIFTS = (0, 1, 7, 29)
 
+# the reference's own smallest test pair (test/imgs/1-240x135/{a,b}.png, what test/diff.sh
+# runs on) at its default parameters (src/stereo.c:7-10): the fixture stores the DECODED
+# uint8 pixels (data of the reference's tests, not source) and the compiled reference's arrays
+REF_PAIR = Path("/root/reference/test/imgs/1-240x135")
+REF_CASES = {
+    "ref_240x135_tor": (0.15, 21, 32, 10, "toroidal"),
+    "ref_240x135_gh":  (0.15, 21, 32, 10, "ghost"),
+}
+
+
+def decode_gray_png(path):
+    from PIL import Image
+    im = Image.open(path)
+    assert im.mode == "L", im.mode              # 8-bit gray, as read_image requires
+    return np.asarray(im, np.uint8).copy()
+
 
 def main():
     if not oracle.ref_available():
         sys.exit("oracle/_ref is missing: run `make -C oracle ref` where /root/reference exists")
     out_dir = Path(__file__).resolve().parent
+    jobs = []
     for name, (w, h, kind, seed, thr, sw, times, lines, mode) in CASES.items():
         left, right = make_pair(w, h, oracle.REF_NUM_SHIFTS, seed=seed, kind=kind)
+        jobs.append((name, left, right, thr, sw, times, lines, mode))
+    if REF_PAIR.is_dir():
+        left, right = decode_gray_png(REF_PAIR / "a.png"), decode_gray_png(REF_PAIR / "b.png")
+        for name, (thr, sw, times, lines, mode) in REF_CASES.items():
+            jobs.append((name, left, right, thr, sw, times, lines, mode))
+    for name, left, right, thr, sw, times, lines, mode in jobs:
         ref = oracle.run_reference(left, right, thr, sw, times, lines, mode)
         keep = {"left": left, "right": right,
                 "params": np.array([thr, sw, times, lines, oracle.MODES[mode]], np.float64)}

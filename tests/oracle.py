@@ -204,3 +204,68 @@ def run_reference(left, right, threshold=0.15, square_width=21, times=32, lines=
         out["stdout"] = p.stdout
         out["returncode"] = p.returncode
     return out
+
+
+# ---------------------------------------------------------------------------
+# full-size images: the same restatement, run on row bands in threads
+# ---------------------------------------------------------------------------
+
+def _bands(h, n_bands):
+    edges = np.linspace(0, h, min(n_bands, h) + 1).astype(int)
+    return [(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+
+
+def _run_threads(jobs, threads):
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:     # ctypes releases the GIL
+        return list(ex.map(lambda j: j(), jobs))
+
+
+def hot_path_banded(le, re, num_shifts, square_width, mode="toroidal", n_bands=64, threads=None):
+    """hot_path() of a large image, bit for bit, computed band by band: the result at a
+    pixel depends only on rows within the window, so each band of rows is taken from an
+    oracle run on the band plus a `half`-row halo (toroidal: the halo wraps around the
+    image; ghost: the image's first / last rows are real borders of the crop as well)."""
+    h, w = le.shape
+    half = square_width // 2
+    threads = threads or min(32, os.cpu_count() or 1)
+    best = np.zeros((h, w), np.int32)
+    web = np.zeros((h, w), np.int32)
+
+    def job(y0, y1):
+        def run():
+            if mode == "toroidal":
+                rows = np.arange(y0 - half, y1 + half) % h
+                lo = half
+            else:
+                a, b = max(0, y0 - half), min(h, y1 + half)
+                rows = np.arange(a, b)
+                lo = y0 - a
+            if len(rows) < 2 * half + 1:        # the oracle needs square_width <= height
+                raise ValueError("band shorter than the window")
+            ob, ow = hot_path(le[rows], re[rows], num_shifts, square_width, mode)
+            best[y0:y1] = ob[lo:lo + y1 - y0]
+            web[y0:y1] = ow[lo:lo + y1 - y0]
+        return run
+    _run_threads([job(a, b) for a, b in _bands(h, n_bands)], threads)
+    return best, web
+
+
+def find_all_edges_banded(gray, threshold=0.15, mode="toroidal", n_bands=32, threads=None):
+    h, w = gray.shape
+    threads = threads or min(32, os.cpu_count() or 1)
+    out = np.zeros((h, w), np.uint8)
+
+    def job(y0, y1):
+        def run():
+            if mode == "toroidal":
+                rows = np.arange(y0 - 1, y1 + 1) % h
+                lo = 1
+            else:
+                a, b = max(0, y0 - 1), min(h, y1 + 1)
+                rows = np.arange(a, b)
+                lo = y0 - a
+            out[y0:y1] = find_all_edges(gray[rows], threshold, mode)[lo:lo + y1 - y0]
+        return run
+    _run_threads([job(a, b) for a, b in _bands(h, n_bands)], threads)
+    return out

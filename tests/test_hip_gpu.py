@@ -264,6 +264,48 @@ def test_baseline_config_full_size_vs_oracle(hip, cfg):
 
 
 @pytest.mark.parametrize("cfg", ["C3", "C5"])
+def test_baseline_config_4k_full_image_vs_oracle(hip, cfg):
+    """The 4K configurations, EVERY pixel: edges, web and best of the whole image against
+    the oracle (its separable window sum, run on row bands with a window-halo in threads)."""
+    w, h, d, sw, mode = CONFIGS[cfg]
+    left, right = make_pair(w, h, d, seed=2)
+    plan = hip.StereoPlan(w, h, d, sw, mode)
+    el, er = plan.find_all_edges(dev(left), dev(right), 0.15)
+    web, best = plan.match_wta(1)
+    oel = oracle.find_all_edges_banded(left, 0.15, mode)
+    oer = oracle.find_all_edges_banded(right, 0.15, mode)
+    assert np.array_equal(host(el)[0], oel) and np.array_equal(host(er)[0], oer), cfg
+    ob, ow = oracle.hot_path_banded(oel, oer, d, sw, mode)
+    assert np.array_equal(host(web)[0], ow), plan.describe()
+    assert np.array_equal(host(best)[0], ob), plan.describe()
+    plan.close()
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+def test_baseline_config_c4_batch_full_size(hip, mode):
+    """C4 as one GPU sees it: a batch of 8 x 1080p pairs, 64 shifts, 7x7, in ONE launch --
+    the 128-row tiles and the two-waves-per-SIMD kernel variant the batch geometry selects.
+    All 8 maps, every pixel, against the oracle (toroidal is the configuration; the ghost
+    border runs the same geometry)."""
+    w, h, d, sw, _ = CONFIGS["C4"]
+    pairs = 8
+    ls, rs = zip(*[make_pair(w, h, d, seed=40 + j) for j in range(pairs)])
+    left, right = np.stack(ls), np.stack(rs)
+    plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
+    g = plan.geometry()
+    assert g["kernel"] == 4 and g["tile_h"] >= 64, plan.describe()      # bit-sliced, tall tiles
+    web, best = plan.run(dev(left), dev(right), 0.15, want_best=True)
+    web_h, best_h = host(web), host(best)
+    for j in range(pairs):
+        oel = oracle.find_all_edges_banded(left[j], 0.15, mode)
+        oer = oracle.find_all_edges_banded(right[j], 0.15, mode)
+        ob, ow = oracle.hot_path_banded(oel, oer, d, sw, mode, n_bands=32)
+        assert np.array_equal(web_h[j], ow), (j, plan.describe())
+        assert np.array_equal(best_h[j], ob), (j, plan.describe())
+    plan.close()
+
+
+@pytest.mark.parametrize("cfg", ["C3", "C5"])
 def test_baseline_config_full_size_properties(hip, cfg):
     """4K configurations: too big for the CPU oracle in seconds, so check (a) bands
     of the full-size result against the oracle run on the same rows (the result at
@@ -504,3 +546,134 @@ def test_hot_path_random_geometries(hip, w, h, d, sw, mode, dens):
     obest, oweb = oracle.hot_path(le, re, d, sw, mode)
     assert np.array_equal(web[0], oweb), desc
     assert np.array_equal(best[0], obest), desc
+
+
+# ---------------------------------------------------------------------------
+# robustness of the launch geometry
+# ---------------------------------------------------------------------------
+
+def edges4_read_columns(w, g):
+    """Host restatement of k_edges_ext4's toroidal address arithmetic: for every lane of
+    the launch grid, the first source column of its dword load (xq) and of its single
+    neighbour byte (xn).  Mirrors csrc/sm_api.hip; the kernel must never read a column
+    outside [0, w)."""
+    ext_px = g["ext_words"] * 32
+    lanes = ((g["ext_words"] * 8 + 255) // 256) * 256
+    lane = np.arange(lanes)
+    xe = lane * 4
+    x = xe - g["pad_l"]
+    in_ext = xe < ext_px
+    over = ext_px - g["pad_l"] - w
+    if w >= g["pad_l"] and w >= over:
+        xq = np.where(x < 0, x + w, np.where(x >= w, x - w, x))
+    else:
+        xq = np.mod(x, w)
+    xq = np.where(in_ext, xq, 0)
+    last = (lane & 63) == 63
+    xn = np.where(last, np.where(xq + 4 == w, 0, xq + 4), np.where(xq == 0, w - 1, xq - 1))
+    return xq, xn
+
+
+@pytest.mark.parametrize("w,h,d,sw", [(640, 480, 30, 21), (1000, 64, 30, 21), (400, 64, 128, 9),
+                                      (240, 135, 30, 21), (64, 48, 16, 5), (3840, 64, 128, 9),
+                                      (1920, 64, 64, 7), (132, 40, 500, 3), (36, 36, 200, 25)])
+def test_edge_kernel_never_reads_outside_a_row(hip, w, h, d, sw):
+    plan = hip.StereoPlan(w, h, d, sw, "toroidal")
+    xq, xn = edges4_read_columns(w, plan.geometry())
+    assert xq.min() >= 0 and xq.max() + 4 <= w, (w, d, sw, int(xq.max()))
+    assert xn.min() >= 0 and xn.max() < w
+    # and the kernel's results are right on an image that ENDS at an allocation boundary
+    left, right = make_pair(w, h, d, seed=5)
+    el, er = plan.find_all_edges(dev(left), dev(right), 0.15)
+    assert np.array_equal(host(el)[0], oracle.find_all_edges(left, 0.15, "toroidal"))
+    assert np.array_equal(host(er)[0], oracle.find_all_edges(right, 0.15, "toroidal"))
+    plan.close()
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+def test_unaligned_buffers_take_the_scalar_paths(hip, mode):
+    """Inputs that are not 4-byte aligned and maps that are not 16-byte aligned must give
+    the same results (the dword / int4 fast paths step aside)."""
+    w, h, d, sw = 256, 96, 64, 7
+    left, right = make_pair(w, h, d, seed=6)
+    plan = hip.StereoPlan(w, h, d, sw, mode)
+    n = w * h
+    raw_l = torch.empty(n + 8, dtype=torch.uint8, device="cuda")
+    raw_r = torch.empty(n + 8, dtype=torch.uint8, device="cuda")
+    l_un = raw_l[1:1 + n].view(h, w); l_un.copy_(dev(left))
+    r_un = raw_r[3:3 + n].view(h, w); r_un.copy_(dev(right))
+    assert l_un.data_ptr() % 4 and r_un.data_ptr() % 4
+    raw_w = torch.empty(n + 8, dtype=torch.int32, device="cuda")
+    raw_b = torch.empty(n + 8, dtype=torch.int32, device="cuda")
+    web_un = raw_w[1:1 + n].view(1, h, w)
+    best_un = raw_b[2:2 + n].view(1, h, w)
+    assert web_un.data_ptr() % 16 and best_un.data_ptr() % 16
+    import ctypes as C
+    from stereomatching_amd.capi import check, lib
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib.sm_run(plan._h, C.c_void_p(l_un.data_ptr()), C.c_void_p(r_un.data_ptr()), 0.15, 1,
+                     C.c_void_p(web_un.data_ptr()), C.c_void_p(best_un.data_ptr()), st))
+    torch.cuda.synchronize()
+    oel = oracle.find_all_edges(left, 0.15, mode)
+    oer = oracle.find_all_edges(right, 0.15, mode)
+    ob, ow = oracle.hot_path(oel, oer, d, sw, mode)
+    assert np.array_equal(host(web_un)[0], ow) and np.array_equal(host(best_un)[0], ob)
+    plan.close()
+
+
+def test_result_buffers_are_validated(hip):
+    plan = hip.StereoPlan(64, 48, 16, 5, "toroidal", max_pairs=2)
+    le, re = rand_edges(64, 48, 1)
+    plan.load_edges(dev(np.stack([le, le])), dev(np.stack([re, re])))
+    with pytest.raises(ValueError):
+        plan.match_wta(2, web=torch.empty((2, 48, 64), dtype=torch.int64, device="cuda"))
+    with pytest.raises(ValueError):
+        plan.match_wta(2, web=torch.empty((2, 48, 60), dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        plan.match_wta(2, web=torch.empty((1, 48, 64), dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        plan.match_wta(2, web=torch.empty((2, 48, 64), dtype=torch.int32))          # host tensor
+    plan.close()
+
+
+def test_plan_on_another_device(hip):
+    """sm_plan_create(device = k > 0): the same parity check on the last visible device."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device")
+    k = torch.cuda.device_count() - 1
+    w, h, d, sw = 320, 96, 128, 9
+    left, right = make_pair(w, h, d, seed=7)
+    plan = hip.StereoPlan(w, h, d, sw, "toroidal", device=k)
+    with torch.cuda.device(k):
+        web, best = plan.run(torch.from_numpy(left).cuda(k), torch.from_numpy(right).cuda(k), 0.15,
+                             want_best=True)
+        torch.cuda.synchronize(k)
+    oel = oracle.find_all_edges(left, 0.15, "toroidal")
+    oer = oracle.find_all_edges(right, 0.15, "toroidal")
+    ob, ow = oracle.hot_path(oel, oer, d, sw, "toroidal")
+    assert np.array_equal(host(web)[0], ow) and np.array_equal(host(best)[0], ob)
+    plan.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` by itself: two child ranks with real kernels, both on
+    device 0 over gloo (SM_BENCH_REHEARSAL; the driver's 8-GPU run uses RCCL)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SM_BENCH_REHEARSAL"] = "1"
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--config", "C4",
+                        "--pairs", "2", "--steps", "6", "--warmup", "2", "--gather"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["bound"] == "valu"
+    assert out["roofline"]["kernel_launches_timed"] >= 6
+    assert "gather_ms" in out

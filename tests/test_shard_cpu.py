@@ -86,4 +86,46 @@ def test_bench_refuses_a_world_size_mismatch():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env,
                        capture_output=True, text=True)
-    assert p.returncode == 2 and "launch with torchrun" in p.stderr
+    assert p.returncode == 2 and "--nproc-per-node 2" in p.stderr
+
+
+def _bench(args, **env):
+    import json
+    import subprocess
+    e = {k: v for k, v in os.environ.items()
+         if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env)
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], env=e, capture_output=True,
+                       text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, [json.loads(l) for l in lines]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` alone (the command the driver issues): the parent
+    starts two child ranks, they rendezvous (gloo here), pass the barriers and the
+    max-over-ranks, and rank 0's single JSON line comes back through the parent.
+    SM_BENCH_DRYRUN replaces the GPU step by a sleep -- this container has no GPU."""
+    p, lines = _bench(["--gpus", "2", "--config", "C4", "--pairs", "8", "--steps", "6", "--warmup", "2"],
+                      SM_BENCH_DRYRUN="1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
+    assert out["dry_run"] is True and out["value"] == 0.0       # can never pass for a measurement
+    assert out["ms_per_step"] >= 0.5
+
+
+def test_bench_propagates_a_failing_rank():
+    p, lines = _bench(["--gpus", "2", "--config", "NOPE", "--steps", "2", "--warmup", "1"],
+                      SM_BENCH_DRYRUN="1")
+    assert p.returncode != 0 and not lines
+
+
+def test_bench_timing_stride_samples_enough_launches():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    for steps in (1, 5, 10, 20, 64, 200, 1000):
+        every = bench.timing_stride(steps)
+        assert 1 <= every <= 8
+        assert (steps + every - 1) // every >= min(steps, 10)
