@@ -142,6 +142,17 @@ int sm_load_edges(sm_plan *plan, const uint8_t *d_edges_left,
 int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d_best,
                  void *stream);
 
+/* The same launch with a NARROW web map: the values are shift indices 1..num_shifts, so
+ * they fit uint8 (num_shifts <= 255) or uint16; d_web then points to W*H elements of that
+ * type per pair.  The reference's type is int32 (src/stereo.cu:304, the D2H copy of
+ * src/image.cu:15-23 moves 4 bytes per pixel); a caller that takes its results to the
+ * host moves 4x / 2x fewer bytes over PCIe this way.  d_best stays int32.              */
+#define SM_WEB_I32 0
+#define SM_WEB_U16 1
+#define SM_WEB_U8  2
+int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web, int web_type,
+                       int32_t *d_best, void *stream);
+
 /* Let consecutive sm_run calls overlap: with the flag set, sm_run launches its
  * edge detection on an internal stream into the other half of a double-buffered
  * workspace, so that it runs beside the (VALU-bound) match kernel of the
@@ -171,6 +182,11 @@ int sm_plan_time_stride(sm_plan *plan, int every);
 int sm_run(sm_plan *plan, const uint8_t *d_gray_left,
            const uint8_t *d_gray_right, double threshold, int pairs,
            int32_t *d_web, int32_t *d_best, void *stream);
+
+/* sm_run with a narrow web map (see sm_match_wta_typed) */
+int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
+                 double threshold, int pairs, void *d_web, int web_type, int32_t *d_best,
+                 void *stream);
 
 /* ---- SAD / SSD cost mode: PARITY UNPINNED ---------------------------------- *
  * BASELINE.json words the hot path as "SAD/SSD cost, window aggregation,

@@ -51,6 +51,42 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def build_diag(verbose: bool = False, name: str = "stamps", flags=()) -> Path:
+    """tools/diag/libstereo_hip_<name>.so: the same sources with -DSM_STAMPS (per-wave
+    time stamps); a diagnostic build, loaded only by tools/wave_timeline.py."""
+    out = ROOT / "tools" / "diag" / f"libstereo_hip_{name}.so"
+    out.parent.mkdir(parents=True, exist_ok=True)
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "sm_internal.h"]
+    if _stale(out, deps):
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-DSM_STAMPS", *flags, f"-I{ROOT / 'include'}", f"-I{CSRC}",
+               *[str(CSRC / s) for s in SOURCES], "-o", str(out)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
+def build_variants(variants: dict, verbose: bool = False, jobs: int = 4) -> None:
+    """Same-device A/B builds for tools/ab_variants.py: name -> extra hipcc flags, each
+    to stereomatching_amd/variants/<name>.so (git-ignored, travels with gpurun)."""
+    import concurrent.futures as cf
+    vdir = PKG / "variants"
+    vdir.mkdir(exist_ok=True)
+    for old in vdir.glob("*.so"):
+        if old.stem not in variants:
+            old.unlink()
+
+    def one(item):
+        name, flags = item
+        cmd = [_hipcc(), *HIPCC_FLAGS, *flags, f"-I{ROOT / 'include'}", f"-I{CSRC}",
+               *[str(CSRC / s) for s in SOURCES], "-o", str(vdir / f"{name}.so")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(one, variants.items()))
+
+
 def build_oracle(verbose: bool = False) -> None:
     """The CPU checker (oracle/liboracle.so) and, where /root/reference exists,
     the compiled reference under oracle/_ref.  Building the checker is not

@@ -11,11 +11,14 @@ import re
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libstereo_hip.so"
+import os as _os
+# diagnostics only (tools/wave_timeline.py loads an instrumented build of the same sources)
+LIB_PATH = Path(_os.environ["SM_HIP_LIB"]) if _os.environ.get("SM_HIP_LIB") else PKG / "libstereo_hip.so"
 HEADER = PKG.parent / "include" / "stereo_hip.h"
 
 SM_OK, SM_ERR_ARG, SM_ERR_HIP, SM_ERR_NOMEM, SM_ERR_ZERO_DIV = range(5)
 SM_TOROIDAL, SM_GHOST = 0, 1
+SM_WEB_I32, SM_WEB_U16, SM_WEB_U8 = 0, 1, 2
 BORDERS = {"toroidal": SM_TOROIDAL, "ghost": SM_GHOST}
 
 
@@ -65,6 +68,8 @@ _SIGNATURES = {
     "sm_find_edges": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp]),
     "sm_load_edges": (_int, [_vp, _vp, _vp, _int, _vp]),
     "sm_match_wta": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "sm_match_wta_typed": (_int, [_vp, _int, _vp, _int, _vp, _vp]),
+    "sm_run_typed": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _int, _vp, _vp]),
     "sm_plan_set_pipelined": (_int, [_vp, _int]),
     "sm_plan_prepare_threshold": (_int, [_vp, C.c_double, _vp]),
     "sm_plan_time_kernels": (_int, [_vp, _int]),

@@ -732,6 +732,7 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
     p->border = border; p->max_pairs = max_pairs;
     int rc = sm_match_configure(p);
     if (rc) { free(p); return rc; }
+    p->g.web_bytes = 4;
 
     p->ext_bytes = (size_t)max_pairs * 2 * (size_t)p->g.ext_image_words * sizeof(u32);
     hipError_t e = hipMalloc((void **)&p->d_ext_buf[0], p->ext_bytes);
@@ -793,6 +794,7 @@ extern "C" void sm_plan_destroy(sm_plan *plan)
     }
     (void)hipStreamDestroy(plan->edge_stream);
     (void)hipEventDestroy(plan->ev_inputs);
+    if (plan->d_web_tmp) (void)hipFree(plan->d_web_tmp);
     (void)hipFree(plan->d_flags);
     (void)hipFree(plan->d_edge_tab);
     free(plan);
@@ -953,11 +955,41 @@ extern "C" int sm_load_edges(sm_plan *plan, const uint8_t *d_edges_left,
     return pack_ext(plan, d_edges_left, d_edges_right, pairs, (hipStream_t)stream);
 }
 
+// int32 web -> uint16 / uint8 (the kernels that have no narrow store path of their own)
+__global__ __launch_bounds__(256) void k_narrow_web(const i32 *__restrict__ src, void *__restrict__ dst,
+                                                   long long n, int bytes)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (bytes == 1) ((u8 *)dst)[p] = (u8)src[p];
+    else ((unsigned short *)dst)[p] = (unsigned short)src[p];
+}
+
 extern "C" int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d_best,
                             void *stream)
 {
+    return sm_match_wta_typed(plan, pairs, d_web, SM_WEB_I32, d_best, stream);
+}
+
+extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int web_type,
+                                  int32_t *d_best, void *stream)
+{
     SM_TRY(check_plan_pairs(plan, pairs, "sm_match_wta"));
-    if (!d_web) return sm_fail(SM_ERR_ARG, "sm_match_wta: d_web is NULL");
+    if (!d_web_any) return sm_fail(SM_ERR_ARG, "sm_match_wta: d_web is NULL");
+    if (web_type != SM_WEB_I32 && web_type != SM_WEB_U16 && web_type != SM_WEB_U8)
+        return sm_fail(SM_ERR_ARG, "sm_match_wta: web_type %d is not SM_WEB_I32/U16/U8", web_type);
+    if ((web_type == SM_WEB_U8 && plan->num_shifts > 255) || (web_type == SM_WEB_U16 && plan->num_shifts > 65535))
+        return sm_fail(SM_ERR_ARG, "sm_match_wta: %d shifts do not fit the requested web type", plan->num_shifts);
+    const int web_bytes = web_type == SM_WEB_I32 ? 4 : web_type == SM_WEB_U16 ? 2 : 1;
+    int32_t *d_web = (int32_t *)d_web_any;
+    const bool via_tmp = web_bytes != 4 && plan->kernel != SM_KERNEL_BS;
+    if (via_tmp) {
+        // kernels without a narrow store path: int32 into a plan-owned map, then narrow
+        const size_t need = (size_t)plan->max_pairs * plan->width * plan->height * sizeof(i32);
+        SM_TRY(use_device(plan->device));
+        if (!plan->d_web_tmp) SM_HIP(hipMalloc((void **)&plan->d_web_tmp, need));
+        d_web = plan->d_web_tmp;
+    }
     if (pairs > plan->pairs_loaded)
         return sm_fail(SM_ERR_ARG, "sm_match_wta: %d pairs requested but edges of only %d are loaded "
                        "(call sm_find_edges or sm_load_edges first)", pairs, plan->pairs_loaded);
@@ -971,10 +1003,19 @@ extern "C" int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d
         // int4 stores need 16-byte aligned maps; otherwise this launch stores scalars
         // (kernel arguments are copied at launch time)
         const int vec_ok = plan->g.vec_ok;
-        if ((((uintptr_t)d_web | (uintptr_t)d_best) & 15) != 0) plan->g.vec_ok = 0;
+        const int kb = via_tmp ? 4 : web_bytes;
+        if (((uintptr_t)d_web & (4 * kb - 1)) != 0 || ((uintptr_t)d_best & 15) != 0) plan->g.vec_ok = 0;
+        plan->g.web_bytes = kb;
         const int rc = sm_match_launch(plan, pairs, d_web, d_best, (hipStream_t)stream);
         plan->g.vec_ok = vec_ok;
+        plan->g.web_bytes = 4;
         if (rc) return rc;
+        if (via_tmp) {
+            const long long n = (long long)pairs * plan->width * plan->height;
+            hipLaunchKernelGGL(k_narrow_web, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                               (hipStream_t)stream, d_web, d_web_any, n, web_bytes);
+            SM_LAUNCH_CHECK("k_narrow_web");
+        }
     }
     if (timed) SM_HIP(hipEventRecord(plan->t_end[plan->timing_n++], (hipStream_t)stream));
     if (plan->pipelined) {
@@ -1054,9 +1095,16 @@ extern "C" int sm_plan_set_pipelined(sm_plan *plan, int enabled)
 extern "C" int sm_run(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
                       double threshold, int pairs, int32_t *d_web, int32_t *d_best, void *stream)
 {
+    return sm_run_typed(plan, d_gray_left, d_gray_right, threshold, pairs, d_web, SM_WEB_I32, d_best, stream);
+}
+
+extern "C" int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
+                            double threshold, int pairs, void *d_web, int web_type, int32_t *d_best,
+                            void *stream)
+{
     if (!plan || !plan->pipelined) {
         SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, stream));
-        return sm_match_wta(plan, pairs, d_web, d_best, stream);
+        return sm_match_wta_typed(plan, pairs, d_web, web_type, d_best, stream);
     }
     // pipelined: edges of this call on the internal stream, into the buffer the
     // previous call's match is NOT reading
@@ -1082,7 +1130,7 @@ extern "C" int sm_run(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *
                          (void *)plan->edge_stream));
     SM_HIP(hipEventRecord(plan->ev_edges[b], plan->edge_stream));
     SM_HIP(hipStreamWaitEvent((hipStream_t)stream, plan->ev_edges[b], 0));
-    return sm_match_wta(plan, pairs, d_web, d_best, stream);
+    return sm_match_wta_typed(plan, pairs, d_web, web_type, d_best, stream);
 }
 
 extern "C" int sm_debug_planes(sm_plan *plan, int pair, int shift, uint8_t *d_match,

@@ -56,6 +56,7 @@ struct MatchGeom {
     int vec_ok;          // rows are 16-byte aligned -> int4 stores
     int lds_bytes;
     int cap2;            // bit-sliced kernel: launch the two-waves-per-SIMD variant
+    int web_bytes;       // bytes per element of the web map of THIS launch: 4 (int32), 2, 1
 };
 
 struct sm_plan {
@@ -77,6 +78,7 @@ struct sm_plan {
     // optional timing of the match launches (sm_plan_time_kernels)
     int timing_cap, timing_n, timing_every, timing_seen;
     hipEvent_t *t_begin, *t_end;
+    i32 *d_web_tmp;      // int32 map for narrow results of kernels without a narrow store path
     i32 *d_flags;        // [0] = zero-interval flag, [1] = has-zero scratch,
                          // [2] = edge table is not of threshold form
     u32 *d_edge_tab;     // 766 x {lo | hi << 16}: edge iff sb <= lo || sb >= hi

@@ -36,6 +36,32 @@
 #define SM_BS_WAVES 2   // min waves per SIMD: keeps VGPR + AGPR <= 256 (one AGPR more halves the occupancy)
 #endif
 
+// Diagnostic build only (-DSM_STAMPS, tools/wave_timeline.py): every wave records
+// when it started, finished staging, finished its warm-up rows and ended (constant
+// 100 MHz s_memrealtime and shader-clock s_memtime) plus where it ran (HW_ID,
+// XCC_ID), into a buffer of its own that nothing else reads.  The product library
+// is built without it and contains none of this.
+#ifdef SM_STAMPS
+__device__ unsigned long long *g_sm_stamps;
+extern "C" int sm_debug_set_stamps(void *buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sm_stamps), &buf, sizeof buf) == hipSuccess ? 0 : SM_ERR_HIP;
+}
+#define SM_STAMP(slot)                                                                          \
+    do {                                                                                        \
+        if (threadIdx.x == 0 && g_sm_stamps) {                                                  \
+            const size_t wg_ = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+            g_sm_stamps[wg_ * 10 + 2 * (slot)] = __builtin_amdgcn_s_memrealtime();              \
+            g_sm_stamps[wg_ * 10 + 2 * (slot) + 1] = __builtin_amdgcn_s_memtime();              \
+            if ((slot) == 0)                                                                    \
+                g_sm_stamps[wg_ * 10 + 8] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | \
+                                            (unsigned)__builtin_amdgcn_s_getreg(63492);         \
+        }                                                                                       \
+    } while (0)
+#else
+#define SM_STAMP(slot) do { } while (0)
+#endif
+
 template <int IMM>
 __device__ __forceinline__ u32 bop(u32 a, u32 b, u32 c)
 {
@@ -51,6 +77,65 @@ __device__ __forceinline__ u32 bop(u32 a, u32 b, u32 c)
 __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh)
 {
     return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// ---------------------------------------------------------------------------
+// LDS reads that stay in flight (SM_BS_PREFETCH).  The compiler issues a row's
+// ds_reads right in front of their first use and the wave then sits in s_waitcnt
+// for the LDS latency, twice per output row, with one other wave on the SIMD to
+// cover for it.  These reads are issued one whole row EARLIER, as inline asm the
+// scheduler cannot sink, and collected with one s_waitcnt where the values are first
+// used.  The compiler does not count them in lgkmcnt; that is safe because LDS
+// operations return in order (its own counted waits can only wait longer) and
+// because lds_wait() below drains the counter before any of the values is read.
+// ---------------------------------------------------------------------------
+#ifndef SM_BS_PREFETCH
+#define SM_BS_PREFETCH 1
+#endif
+typedef unsigned long long u64;
+struct RawRow { u64 l01; u32 l2; u64 r01, r23; };      // 3 left words, 4 right words
+struct RawCentre { u32 l; u64 r01; u32 r2; };          // centre word, 3 right words
+__device__ __forceinline__ void lds_issue(RawRow &o, u32 aL, u32 aR)
+{
+    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(o.l01) : "v"(aL));
+    asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(o.l2) : "v"(aL));
+    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(o.r01) : "v"(aR));
+    asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=v"(o.r23) : "v"(aR));
+}
+__device__ __forceinline__ void lds_issue(RawCentre &o, u32 aL, u32 aR)
+{
+    asm volatile("ds_read_b32 %0, %1" : "=v"(o.l) : "v"(aL));
+    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(o.r01) : "v"(aR));
+    asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(o.r2) : "v"(aR));
+}
+// every value read above becomes valid here (and not before: the operands tie them to it)
+__device__ __forceinline__ void lds_wait(RawRow &a, RawRow &b, RawCentre &c)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.l01), "+v"(a.l2), "+v"(a.r01), "+v"(a.r23), "+v"(b.l01), "+v"(b.l2),
+                   "+v"(b.r01), "+v"(b.r23), "+v"(c.l), "+v"(c.r01), "+v"(c.r2));
+}
+__device__ __forceinline__ void lds_wait(RawRow &a)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.l01), "+v"(a.l2), "+v"(a.r01), "+v"(a.r23));
+}
+
+// result stores: 0 = nt (streaming hint, the line still stays in L2), 1 = sc1
+// (write-through: the bytes leave L2 while the kernel runs instead of in one
+// write-back burst when it ends), 2 = plain
+#ifndef SM_BS_STORE
+#define SM_BS_STORE 0
+#endif
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_map4(i32 *p, v4i v)
+{
+#if SM_BS_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#elif SM_BS_STORE == 2
+    *reinterpret_cast<v4i *>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<v4i *>(p));
+#endif
 }
 
 constexpr int bits_for(int v) { int b = 0; while ((1 << b) <= v) b++; return b; }   // v < 2^b
@@ -190,6 +275,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     if (CAP2) asm volatile("" ::: "v175");
     const int tid = threadIdx.x;
     const int pair = blockIdx.z;
+    SM_STAMP(0);
     int tile_x, tile_y;
     sm_xcd_tile(g.tiles_x, g.tiles_y, tile_x, tile_y);
     const int tx0 = tile_x * g.tw;
@@ -213,6 +299,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
         }
     }
     __syncthreads();
+    SM_STAMP(1);
 
     // ---- lane role
     const int s = tid & (g.nl - 1);           // which 16 shifts
@@ -262,6 +349,14 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
 #pragma unroll
         for (int i = 0; i < N; i++) v.lv[i] = i ? alignbit(l1, l0, i) : l0;
     };
+    auto views_of = [&](const RawRow &q, RowViews &v) {
+        const u32 a0 = (u32)q.l01, a1 = (u32)(q.l01 >> 32), a2 = q.l2;
+        const u32 r0 = (u32)q.r01, r1 = (u32)(q.r01 >> 32), r2 = (u32)q.r23, r3 = (u32)(q.r23 >> 32);
+        const u32 l0 = alignbit(a1, a0, shL), l1 = alignbit(a2, a1, shL);
+        v.rw[0] = alignbit(r1, r0, shR); v.rw[1] = alignbit(r2, r1, shR); v.rw[2] = alignbit(r3, r2, shR);
+#pragma unroll
+        for (int i = 0; i < N; i++) v.lv[i] = i ? alignbit(l1, l0, i) : l0;
+    };
     auto rview = [&](const RowViews &v, int j) -> u32 {
         return (j & 31) ? alignbit(v.rw[(j >> 5) + 1], v.rw[j >> 5], j & 31) : v.rw[j >> 5];
     };
@@ -292,10 +387,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
         }
     };
     // steady state: one row in and one row out, applied as a single signed difference
-    auto slide_both = [&](int srow_new, int srow_old) {
-        RowViews vn, vo;
-        load_views(srow_new, vn);
-        load_views(srow_old, vo);
+    auto slide_views = [&](const RowViews &vn, const RowViews &vo) {
         u32 wn[N], wo[N];
 #pragma unroll
         for (int i = 0; i < N - 1; i++) { wn[i + 1] = rview(vn, i); wo[i + 1] = rview(vo, i); }
@@ -311,6 +403,14 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
             addsub_planes<SB, HB>(S[dd], hn, ho);
         }
     };
+#if !SM_BS_PREFETCH
+    auto slide_both = [&](int srow_new, int srow_old) {
+        RowViews vn, vo;
+        load_views(srow_new, vn);
+        load_views(srow_old, vo);
+        slide_views(vn, vo);
+    };
+#endif
 
     // Staged row e is image row ty0 - HALF + e.  Ghost rows outside the image need no
     // special case: their ext rows are all zero in BOTH images, so every tap reads
@@ -324,14 +424,36 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     // 16 x SB register copies per row for it).
 #pragma unroll 1
     for (int e = 0; e < N; e++) slide_in(e);
+    SM_STAMP(2);
 
+#if SM_BS_PREFETCH
+    // byte addresses (LDS offsets: the low half of the flat address) of this lane's words
+    // in staged row 0, and the row strides; the reads of iteration t + 1 are issued while
+    // iteration t computes
+    const u32 ldsL = (u32)(uintptr_t)pL, ldsR = (u32)(uintptr_t)pR;
+    const u32 sL = 4u * plw, sR = 4u * prw;
+    u32 aNewL = ldsL + 4u * wL + sL * N, aNewR = ldsR + 4u * wR + sR * N;     // staged row N
+    u32 aCenL = ldsL + 4u * wLc + sL * HALF, aCenR = ldsR + 4u * wRc + sR * HALF;
+    RawRow qn, qo;
+    RawCentre qc;
+    lds_issue(qc, aCenL, aCenR);
+    lds_issue(qn, aNewL, aNewR);
+    lds_issue(qo, aNewL - sL * N, aNewR - sR * N);
+#endif
 #pragma unroll 1
     for (int t = 0;;) {
         // ---- winner-take-all of output row t over this lane's 16 shifts
         const int y = ty0 + t;
+#if SM_BS_PREFETCH
+        lds_wait(qn, qo, qc);
+        const u32 lc = qc.l;
+        const u32 c0_ = (u32)qc.r01, c1_ = (u32)(qc.r01 >> 32), c2_ = qc.r2;
+        const u32 rc0 = alignbit(c1_, c0_, shRc), rc1 = alignbit(c2_, c1_, shRc);
+#else
         const u32 lc = pL[(t + HALF) * plw + wLc];
         const u32 *rrc = pR + (t + HALF) * prw + wRc;
         const u32 rc0 = alignbit(rrc[1], rrc[0], shRc), rc1 = alignbit(rrc[2], rrc[1], shRc);
+#endif
 
         u32 B[SB], arg[ABMAX];
 #pragma unroll
@@ -419,31 +541,77 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
                 }
                 const int x = x0 + p0;
                 const size_t o = ((size_t)pair * g.h + y) * g.w + x;
-                if (cw == 4 && g.vec_ok && x + 4 <= g.w) {
-                    // streaming stores: the maps are written once and never read here; kept
-                    // write-back in L2 they are flushed in one burst when the kernel ends
-                    typedef int v4i __attribute__((ext_vector_type(4)));
-                    const v4i wq = {wv[0], wv[1], wv[2], wv[3]};
-                    __builtin_nontemporal_store(wq, reinterpret_cast<v4i *>(web + o));
-                    if (best) {
-                        const v4i bq = {bv[0], bv[1], bv[2], bv[3]};
-                        __builtin_nontemporal_store(bq, reinterpret_cast<v4i *>(best + o));
+                const bool vec = cw == 4 && g.vec_ok && x + 4 <= g.w;
+                // streaming stores: the maps are written once and never read here
+                if (g.web_bytes == 4) {
+                    if (vec) {
+                        const v4i wq = {wv[0], wv[1], wv[2], wv[3]};
+                        store_map4(web + o, wq);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (q < cw && x + q < g.w) web[o + q] = wv[q];
+                    }
+                } else if (g.web_bytes == 1) {
+                    // narrow maps (sm_match_wta_typed): the same values as uint8 / uint16
+                    u8 *web8 = reinterpret_cast<u8 *>(web);
+                    if (vec) {
+                        u32 pk = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) pk |= (u32)(wv[q] & 255) << (8 * q);
+                        __builtin_nontemporal_store(pk, reinterpret_cast<u32 *>(web8 + o));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (q < cw && x + q < g.w) web8[o + q] = (u8)wv[q];
                     }
                 } else {
+                    unsigned short *web16 = reinterpret_cast<unsigned short *>(web);
+                    if (vec) {
+                        typedef u32 v2u __attribute__((ext_vector_type(2)));
+                        const v2u pk = {(u32)wv[0] | ((u32)wv[1] << 16), (u32)wv[2] | ((u32)wv[3] << 16)};
+                        __builtin_nontemporal_store(pk, reinterpret_cast<v2u *>(web16 + o));
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (q < cw && x + q < g.w) {
-                            web[o + q] = wv[q];
-                            if (best) best[o + q] = bv[q];
-                        }
+                        for (int q = 0; q < 4; q++)
+                            if (q < cw && x + q < g.w) web16[o + q] = (unsigned short)wv[q];
+                    }
+                }
+                if (best) {
+                    if (vec) {
+                        const v4i bq = {bv[0], bv[1], bv[2], bv[3]};
+                        store_map4(best + o, bq);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (q < cw && x + q < g.w) best[o + q] = bv[q];
+                    }
                 }
             }
         }
 
         // ---- slide the window down: staged row t + N - 1 in, staged row t - 1 out
         if (++t >= rows_out) break;
+#if SM_BS_PREFETCH
+        {
+            // cut the views of this slide out of the raw words, which frees their
+            // registers for the reads of the NEXT iteration: a whole slide ahead of use
+            RowViews vn, vo;
+            views_of(qn, vn);
+            views_of(qo, vo);
+            aNewL += sL; aNewR += sR; aCenL += sL; aCenR += sR;
+            lds_issue(qc, aCenL, aCenR);
+            if (t + 1 < rows_out) {               // uniform; the last row slides no further
+                lds_issue(qn, aNewL, aNewR);
+                lds_issue(qo, aNewL - sL * N, aNewR - sR * N);
+            }
+            slide_views(vn, vo);
+        }
+#else
         slide_both(t + N - 1, t - 1);
+#endif
     }
+    SM_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------

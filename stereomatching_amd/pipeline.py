@@ -33,6 +33,9 @@ class AlgorithmParams:
     lines_to_draw: int = DEFAULT_LINES
 
 
+WEB_TYPES = {torch.int32: capi.SM_WEB_I32, torch.uint16: capi.SM_WEB_U16, torch.uint8: capi.SM_WEB_U8}
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -119,12 +122,12 @@ class StereoPlan:
             raise ValueError(f"{name}: shape {tuple(t.shape)} is not (pairs, {self.height}, {self.width})")
         return t
 
-    def _out(self, t, pairs, name):
+    def _out(self, t, pairs, name, dtype=torch.int32):
         """A caller-supplied result buffer gets the same checks as an input (a wrong
         buffer would otherwise become an out-of-bounds device write)."""
         if t is None:
-            return self._new(pairs, torch.int32)
-        t = self._images(t, torch.int32, name)
+            return self._new(pairs, dtype)
+        t = self._images(t, dtype, name)
         if t.shape[0] < pairs:
             raise ValueError(f"{name}: room for {t.shape[0]} maps, {pairs} pairs requested")
         return t
@@ -153,24 +156,26 @@ class StereoPlan:
         return le.shape[0]
 
     # ---- step 2: the hot path ----------------------------------------------
-    def match_wta(self, pairs=1, want_best=True, web=None, best=None):
+    def match_wta(self, pairs=1, want_best=True, web=None, best=None, web_dtype=torch.int32):
         """fillup_matches + fillup_scores + find_highest_scoring_shifts
-        (src/stereo.cu:127-225) in one launch -> (web, best)."""
-        web = self._out(web, pairs, "web")
+        (src/stereo.cu:127-225) in one launch -> (web, best).  web_dtype torch.uint16 /
+        torch.uint8 asks for the narrow map (sm_match_wta_typed); int32 is the reference's."""
+        web = self._out(web, pairs, "web", web_dtype)
         best = self._out(best, pairs, "best") if want_best else None
-        check(lib.sm_match_wta(self._h, pairs, _ptr(web), _ptr(best if want_best else None),
-                               self._stream()))
+        check(lib.sm_match_wta_typed(self._h, pairs, _ptr(web), WEB_TYPES[web_dtype],
+                                     _ptr(best if want_best else None), self._stream()))
         return web, (best if want_best else None)
 
-    def run(self, left, right, threshold=DEFAULT_THRESHOLD, want_best=False, web=None, best=None):
+    def run(self, left, right, threshold=DEFAULT_THRESHOLD, want_best=False, web=None, best=None,
+            web_dtype=torch.int32):
         """steps 1+2: uint8 pairs in, web (and optionally best) out."""
         left = self._images(left, torch.uint8, "left")
         right = self._images(right, torch.uint8, "right")
         pairs = left.shape[0]
-        web = self._out(web, pairs, "web")
+        web = self._out(web, pairs, "web", web_dtype)
         best = self._out(best, pairs, "best") if want_best else None
-        check(lib.sm_run(self._h, _ptr(left), _ptr(right), float(threshold), pairs, _ptr(web),
-                         _ptr(best if want_best else None), self._stream()))
+        check(lib.sm_run_typed(self._h, _ptr(left), _ptr(right), float(threshold), pairs, _ptr(web),
+                               WEB_TYPES[web_dtype], _ptr(best if want_best else None), self._stream()))
         return web, (best if want_best else None)
 
     def cost_wta(self, left, right, cost="sad", want_best=True):

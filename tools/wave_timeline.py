@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of one match launch (diagnostic build with -DSM_STAMPS).
+
+    python -c "from stereomatching_amd import build; build.build_diag(True)"   # build box
+    gpurun -- 'python3 tools/wave_timeline.py C3 1 > gpurun_out/timeline_C3.txt'
+
+Every wave stamps start / staged / warmed-up / end with the constant 100 MHz
+counter (s_memrealtime) and the shader clock (s_memtime) plus its HW_ID / XCC_ID.
+Prints: launch span, when waves start and end, wave lifetime distribution, waves per
+SIMD, the phase split, and the shader clock the waves saw.
+"""
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ["SM_HIP_LIB"] = str(ROOT / "tools" / "diag" /
+                               f"libstereo_hip_{os.environ.get('SM_DIAG', 'stamps')}.so")
+
+import ctypes as C  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from stereomatching_amd import capi, pipeline  # noqa: E402
+from stereomatching_amd.synth import CONFIGS, make_pair  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+w, h, d, sw, mode = CONFIGS[cfg]
+plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
+g = plan.geometry()
+print(plan.describe())
+ls, rs = zip(*[make_pair(w, h, d, seed=j) for j in range(pairs)])
+left, right = torch.from_numpy(np.stack(ls)).cuda(), torch.from_numpy(np.stack(rs)).cuda()
+plan.find_all_edges(left, right, want_edges=False)
+n_wg = g["tiles_x"] * g["tiles_y"] * pairs
+stamps = torch.zeros((n_wg, 10), dtype=torch.int64, device="cuda")
+web = None
+for _ in range(5):                       # warm: clocks, code object
+    web, _ = plan.match_wta(pairs, want_best=False, web=web)
+torch.cuda.synchronize()
+capi.lib.sm_debug_set_stamps.argtypes = [C.c_void_p]
+assert capi.lib.sm_debug_set_stamps(C.c_void_p(stamps.data_ptr())) == 0
+for rep in range(3):
+    stamps.zero_()
+    torch.cuda.synchronize()
+    # back to back with a preceding launch of the same kernel, as in the bench loop
+    plan.match_wta(pairs, want_best=False, web=web)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    plan.match_wta(pairs, want_best=False, web=web)
+    e1.record()
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().astype(np.int64)
+    rt = s[:, 0:8:2].astype(np.float64) * 0.01          # us (100 MHz)
+    ck = s[:, 1:8:2].astype(np.float64)
+    hw = s[:, 8]
+    t0 = rt[:, 0].min()
+    rt -= t0
+    life = rt[:, 3] - rt[:, 0]
+    print(f"--- rep {rep}: event time {e0.elapsed_time(e1) * 1e3:.1f} us; first wave start -> last wave "
+          f"end {rt[:, 3].max():.1f} us; waves {n_wg}")
+    q = [0, 1, 10, 50, 90, 99, 100]
+    print("  wave start  (us) pct", q, np.percentile(rt[:, 0], q).round(1))
+    print("  wave end    (us) pct", q, np.percentile(rt[:, 3], q).round(1))
+    print("  lifetime    (us) pct", q, np.percentile(life, q).round(1))
+    print("  stage / warm-up / rows (us, median):", np.median(rt[:, 1] - rt[:, 0]).round(2),
+          np.median(rt[:, 2] - rt[:, 1]).round(2), np.median(rt[:, 3] - rt[:, 2]).round(2))
+    clk = (ck[:, 3] - ck[:, 0]) / np.maximum(life, 1e-9) / 1e3
+    print("  shader clock seen by waves (GHz) pct", q, np.percentile(clk, q).round(3))
+    hwid = hw & 0xffffffff
+    xcc = (hw >> 32) & 0xf
+    simd = (hwid >> 4) & 3
+    cu = (hwid >> 8) & 0xf
+    sh = (hwid >> 12) & 1
+    se = (hwid >> 13) & 7
+    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    simd_key = key * 4 + simd
+    uniq, cnt = np.unique(simd_key, return_counts=True)
+    print(f"  distinct CUs {len(np.unique(key))}, distinct SIMDs {len(uniq)}; waves per SIMD histogram:",
+          dict(zip(*np.unique(cnt, return_counts=True))))
+    # overlap: how many waves were alive on a SIMD at once (max), and second-round waves
+    late = rt[:, 0] > 5.0
+    print(f"  waves starting later than 5 us after the first: {int(late.sum())}"
+          f" (median start {np.median(rt[late, 0]) if late.any() else 0:.1f} us)")
+    for x in range(8):
+        m = xcc == x
+        if m.any():
+            print(f"    XCC {x}: waves {int(m.sum()):5d}  start max {rt[m, 0].max():7.1f}  end max "
+                  f"{rt[m, 3].max():7.1f}  lifetime median {np.median(life[m]):7.1f}")
