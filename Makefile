@@ -7,6 +7,7 @@
 #
 #   stereomatch, stereomatch-ghost   CPU: the oracle's CLI (checker side of diff.sh)
 #   stereopar,   stereopar-ghost     GPU: C host code over include/stereo_hip.h
+#   stereopar-batch                  GPU: a list of pairs over all visible devices
 #
 # hipcc builds the device library once; everything else is gcc.
 
@@ -30,8 +31,9 @@ LINKDEV := -Lstereomatching_amd -lstereo_hip -Wl,-rpath,'$$ORIGIN/../stereomatch
 
 CPU_PROGRAMS := $(O)/stereomatch $(O)/stereomatch-ghost
 GPU_PROGRAMS := $(O)/stereopar $(O)/stereopar-ghost
+BATCH_PROGRAM := $(O)/stereopar-batch
 
-all: $(CPU_PROGRAMS) $(GPU_PROGRAMS)
+all: $(CPU_PROGRAMS) $(GPU_PROGRAMS) $(BATCH_PROGRAM)
 
 $(O):
 	mkdir -p $@
@@ -53,6 +55,10 @@ $(CPU_PROGRAMS): oracle/stereomatch_cli.c $(O)/image.o $(O)/oracle.o
 
 $(GPU_PROGRAMS): $(HOSTDIR)/stereopar.c $(O)/image.o $(O)/image_gpu.o $(DEVLIB)
 	$(CC) $(CFLAGS) $(if $(findstring ghost,$@),-DGHOST) $(filter %.c %.o,$^) -o $@ $(LINKDEV) -lm
+
+# a batch of pairs over all visible GPUs (not in the reference: its programs do one pair)
+$(BATCH_PROGRAM): $(HOSTDIR)/stereopar_batch.c $(O)/image.o $(DEVLIB)
+	$(CC) $(CFLAGS) $(filter %.c %.o,$^) -o $@ $(LINKDEV) -lm -lpthread
 
 clean:
 	rm -rf debug timing release *.ppm

@@ -242,6 +242,18 @@ int sm_draw_contour_map(sm_plan *plan, const int32_t *d_web,
                         const int32_t *d_minmax, int num_lines, int pairs,
                         uint8_t *d_out, void *stream);
 
+/* The whole of step 3 (fill_web_holes, image min/max, draw_contour_map:
+ * src/stereo.cu:325-333) with ONE synchronisation instead of one per stage.  Same
+ * results as sm_fill_web_holes + sm_min_max + sm_draw_contour_map + sm_plan_status:
+ * d_out receives the contour image of the hole-filled map, d_minmax its {min, max},
+ * *result_in_tmp tells which of d_web / d_tmp holds the hole-filled map.  The stages
+ * are queued speculating that the map has no zero pixel (hole filling then is the
+ * identity; a web from sm_match_wta never has one) and one pass over the map verifies
+ * it; a map that does have holes takes the staged route.  Returns SM_ERR_ZERO_DIV
+ * for a zero contour interval.  Synchronises the stream.                            */
+int sm_step3(sm_plan *plan, int32_t *d_web, int32_t *d_tmp, int times, int num_lines,
+             int pairs, int32_t *d_minmax, uint8_t *d_out, int *result_in_tmp, void *stream);
+
 /* synchronises the stream and returns SM_ERR_ZERO_DIV if a contour launch
  * since the last call met a zero interval, else SM_OK                       */
 int sm_plan_status(sm_plan *plan, void *stream);

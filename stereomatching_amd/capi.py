@@ -84,6 +84,7 @@ _SIGNATURES = {
     "sm_min_max": (_int, [_vp, _vp, _int, _vp, _vp]),
     "sm_draw_contour_map": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),
     "sm_plan_status": (_int, [_vp, _vp]),
+    "sm_step3": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp, _intp, _vp]),
 }
 
 

@@ -579,6 +579,46 @@ __global__ __launch_bounds__(256) void k_minmax(const i32 *__restrict__ a, long 
     }
 }
 
+// min / max of each pair's image AND "some pixel is 0" (the hole-fill stage only ever
+// changes pixels that are 0), in one pass over the maps
+__global__ __launch_bounds__(256) void k_minmax_zero(const i32 *__restrict__ a, long long n,
+                                                     i32 *__restrict__ mm, i32 *__restrict__ zero_flag)
+{
+    const size_t base = (size_t)blockIdx.y * n;
+    i32 lo = INT_MAX, hi = INT_MIN;
+    bool z = false;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (long long)gridDim.x * blockDim.x) {
+        const i32 v = a[base + p];
+        lo = min(lo, v);
+        hi = max(hi, v);
+        z |= v == 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        hi = max(hi, __shfl_xor(hi, off));
+    }
+    const bool any_z = __ballot(z) != 0;
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[2 * blockIdx.y], lo);
+        atomicMax(&mm[2 * blockIdx.y + 1], hi);
+        if (any_z) atomicOr(zero_flag, 1);
+    }
+}
+
+// hand the plan's flags to the host: one lane copies them into pinned host memory the
+// host reads after synchronising the stream (no 4-byte hipMemcpy to pageable memory,
+// which costs tens of microseconds), and clears the ones in `clear_mask`
+__global__ void k_publish_flags(i32 *__restrict__ d_flags, i32 *__restrict__ h_flags, int clear_mask)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < 4; i++) {
+            h_flags[i] = d_flags[i];
+            if ((clear_mask >> i) & 1) d_flags[i] = 0;
+        }
+    }
+}
+
 // src/stereo.cu:261-274
 __global__ __launch_bounds__(256) void k_contour(const i32 *__restrict__ web,
                                                  const i32 *__restrict__ mm, int lines,
@@ -603,6 +643,8 @@ __global__ __launch_bounds__(256) void k_contour(const i32 *__restrict__ web,
 // ---------------------------------------------------------------------------
 
 static void free_timing(sm_plan *plan);
+static int run_sweeps(sm_plan *plan, i32 *d_web, i32 *d_tmp, int times, int pairs, int *result_in_tmp,
+                      hipStream_t st);
 
 static int use_device(int device)
 {
@@ -747,6 +789,7 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_inputs, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flags, 4 * sizeof(i32));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_edge_tab, 768 * sizeof(u32));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_flags, 4 * sizeof(i32), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemset(p->d_ext, 0, p->ext_bytes);
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(i32));
     if (e != hipSuccess) {
@@ -759,6 +802,7 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
         if (p->ev_inputs) (void)hipEventDestroy(p->ev_inputs);
         if (p->d_flags) (void)hipFree(p->d_flags);
         if (p->d_edge_tab) (void)hipFree(p->d_edge_tab);
+        if (p->h_flags) (void)hipHostFree(p->h_flags);
         free(p);
         return sm_fail(e == hipErrorOutOfMemory ? SM_ERR_NOMEM : SM_ERR_HIP,
                        "sm_plan_create: workspace allocation failed: %s", hipGetErrorString(e));
@@ -771,7 +815,8 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
         const void *fns[] = {
             (const void *)k_edge_thresholds, (const void *)k_pack_ext, (const void *)k_debug_planes,
             (const void *)k_fill_holes_step, (const void *)k_count_zeros, (const void *)k_minmax_init,
-            (const void *)k_minmax, (const void *)k_contour,
+            (const void *)k_minmax, (const void *)k_contour, (const void *)k_minmax_zero,
+            (const void *)k_publish_flags,
             gh ? (const void *)k_edges_ext4<true, true> : (const void *)k_edges_ext4<false, true>,
             gh ? (const void *)k_edges_ext<true, true> : (const void *)k_edges_ext<false, true>,
         };
@@ -797,6 +842,7 @@ extern "C" void sm_plan_destroy(sm_plan *plan)
     if (plan->d_web_tmp) (void)hipFree(plan->d_web_tmp);
     (void)hipFree(plan->d_flags);
     (void)hipFree(plan->d_edge_tab);
+    (void)hipHostFree(plan->h_flags);
     free(plan);
 }
 
@@ -827,6 +873,17 @@ extern "C" int sm_plan_geometry(const sm_plan *plan, sm_geometry *out)
 extern "C" size_t sm_plan_workspace_bytes(const sm_plan *plan)
 {
     return plan ? 2 * plan->ext_bytes + 4 * sizeof(i32) + 768 * sizeof(u32) : 0;
+}
+
+// synchronise `st` and return the plan's flags as they were at that point; flags in
+// clear_mask are reset on the device
+static int read_flags(sm_plan *plan, hipStream_t st, int clear_mask, i32 out[4])
+{
+    hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, plan->d_flags, plan->h_flags, clear_mask);
+    SM_LAUNCH_CHECK("k_publish_flags");
+    SM_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 4; i++) out[i] = plan->h_flags[i];
+    return SM_OK;
 }
 
 static int check_plan_pairs(const sm_plan *plan, int pairs, const char *who)
@@ -865,10 +922,9 @@ static int ensure_edge_tables(sm_plan *plan, double threshold, hipStream_t st)
     SM_LAUNCH_CHECK("k_edge_thresholds");
     // read the verdict back once per new threshold (not in the steady state): it
     // selects the kernel instantiation
-    i32 bad = 0;
-    SM_HIP(hipMemcpyAsync(&bad, &plan->d_flags[2], sizeof(i32), hipMemcpyDeviceToHost, st));
-    SM_HIP(hipStreamSynchronize(st));
-    plan->tab_ok = bad == 0;
+    i32 f[4];
+    SM_TRY(read_flags(plan, st, 0, f));
+    plan->tab_ok = f[2] == 0;
     plan->tab_threshold = threshold;
     plan->tab_valid = 1;
     return SM_OK;
@@ -885,10 +941,9 @@ extern "C" int sm_debug_edge_table_fast(sm_plan *plan, double threshold, uint8_t
     hipLaunchKernelGGL(k_edge_table_fast, dim3(3, 766), dim3(256), 0, st, plan->d_edge_tab,
                        edge_neg_t(threshold), d_table);
     SM_LAUNCH_CHECK("k_edge_table_fast");
-    i32 bad = 0;
-    SM_HIP(hipMemcpyAsync(&bad, &plan->d_flags[2], sizeof(i32), hipMemcpyDeviceToHost, st));
-    SM_HIP(hipStreamSynchronize(st));
-    *not_threshold_form = bad;
+    i32 f[4];
+    SM_TRY(read_flags(plan, st, 0, f));
+    *not_threshold_form = f[2];
     return SM_OK;
 }
 
@@ -1183,23 +1238,11 @@ extern "C" int sm_fill_web_holes(sm_plan *plan, int32_t *d_web, int32_t *d_tmp, 
     hipLaunchKernelGGL(k_count_zeros, dim3(1024), dim3(256), 0, st, d_web, n * pairs,
                        &plan->d_flags[1]);
     SM_LAUNCH_CHECK("k_count_zeros");
-    i32 has_zero = 0;
-    SM_HIP(hipMemcpyAsync(&has_zero, &plan->d_flags[1], sizeof(i32), hipMemcpyDeviceToHost, st));
-    SM_HIP(hipStreamSynchronize(st));
-    if (!has_zero) return SM_OK;
+    i32 f[4];
+    SM_TRY(read_flags(plan, st, 0, f));
+    if (!f[1]) return SM_OK;
 
-    // tmp <- web, then `times` sweeps with the two buffers trading places
-    // (src/stereo.cu:247-256,:328)
-    SM_HIP(hipMemcpyAsync(d_tmp, d_web, sizeof(i32) * n * pairs, hipMemcpyDeviceToDevice, st));
-    i32 *cur = d_web, *oth = d_tmp;
-    const dim3 grid((unsigned)((n + 255) / 256), pairs), block(256);
-    for (int i = 0; i < times; i++) {
-        hipLaunchKernelGGL(k_fill_holes_step, grid, block, 0, st, cur, oth, plan->width, n);
-        i32 *t = cur; cur = oth; oth = t;
-    }
-    SM_LAUNCH_CHECK("k_fill_holes_step");
-    *result_in_tmp = cur == d_tmp;
-    return SM_OK;
+    return run_sweeps(plan, d_web, d_tmp, times, pairs, result_in_tmp, st);
 }
 
 extern "C" int sm_min_max(sm_plan *plan, const int32_t *d_image, int pairs, int32_t *d_minmax,
@@ -1232,16 +1275,75 @@ extern "C" int sm_draw_contour_map(sm_plan *plan, const int32_t *d_web, const in
     return SM_OK;
 }
 
+static int run_sweeps(sm_plan *plan, i32 *d_web, i32 *d_tmp, int times, int pairs, int *result_in_tmp,
+                      hipStream_t st)
+{
+    // tmp <- web, then `times` sweeps with the two buffers trading places
+    // (src/stereo.cu:247-256,:328)
+    const long long n = (long long)plan->width * plan->height;
+    SM_HIP(hipMemcpyAsync(d_tmp, d_web, sizeof(i32) * n * pairs, hipMemcpyDeviceToDevice, st));
+    i32 *cur = d_web, *oth = d_tmp;
+    const dim3 grid((unsigned)((n + 255) / 256), pairs), block(256);
+    for (int i = 0; i < times; i++) {
+        hipLaunchKernelGGL(k_fill_holes_step, grid, block, 0, st, cur, oth, plan->width, n);
+        i32 *t = cur; cur = oth; oth = t;
+    }
+    SM_LAUNCH_CHECK("k_fill_holes_step");
+    *result_in_tmp = cur == d_tmp;
+    return SM_OK;
+}
+
+extern "C" int sm_step3(sm_plan *plan, int32_t *d_web, int32_t *d_tmp, int times, int num_lines,
+                        int pairs, int32_t *d_minmax, uint8_t *d_out, int *result_in_tmp, void *stream)
+{
+    SM_TRY(check_plan_pairs(plan, pairs, "sm_step3"));
+    if (!d_web || !d_tmp || !d_minmax || !d_out || !result_in_tmp)
+        return sm_fail(SM_ERR_ARG, "sm_step3: NULL argument");
+    SM_TRY(use_device(plan->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)plan->width * plan->height;
+    *result_in_tmp = 0;
+    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    const dim3 mm_grid(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), pairs);
+    const dim3 px_grid((unsigned)((n + 255) / 256), pairs);
+
+    // Speculate that the map has no zero pixel (a web from the hot path never has: a
+    // winning shift is stored as shift + 1): then hole filling is the identity, the
+    // min/max pass over the unfilled map is the one the contour stage needs, and ONE
+    // pass also proves the speculation.  Everything is queued before the only sync.
+    SM_HIP(hipMemsetAsync(&plan->d_flags[1], 0, sizeof(i32), st));
+    hipLaunchKernelGGL(k_minmax_init, dim3((pairs + 63) / 64), dim3(64), 0, st, d_minmax, pairs);
+    hipLaunchKernelGGL(k_minmax_zero, mm_grid, dim3(256), 0, st, d_web, n, d_minmax, &plan->d_flags[1]);
+    hipLaunchKernelGGL(k_contour, px_grid, dim3(256), 0, st, d_web, d_minmax, num_lines, n, d_out,
+                       plan->d_flags);
+    SM_LAUNCH_CHECK("k_contour");
+    i32 f[4];
+    SM_TRY(read_flags(plan, st, 1, f));
+    if (f[1] && times > 0) {
+        // there ARE holes: do it the long way (sweeps, then min/max and contour again)
+        SM_TRY(run_sweeps(plan, d_web, d_tmp, times, pairs, result_in_tmp, st));
+        const i32 *filled = *result_in_tmp ? d_tmp : d_web;
+        hipLaunchKernelGGL(k_minmax_init, dim3((pairs + 63) / 64), dim3(64), 0, st, d_minmax, pairs);
+        hipLaunchKernelGGL(k_minmax, mm_grid, dim3(256), 0, st, filled, n, d_minmax);
+        hipLaunchKernelGGL(k_contour, px_grid, dim3(256), 0, st, filled, d_minmax, num_lines, n, d_out,
+                           plan->d_flags);
+        SM_LAUNCH_CHECK("k_contour");
+        SM_TRY(read_flags(plan, st, 1, f));
+    }
+    if (f[0])
+        return sm_fail(SM_ERR_ZERO_DIV, "contour interval is zero ((max-min)/lines == 0): the "
+                       "reference divides by it");
+    return SM_OK;
+}
+
 extern "C" int sm_plan_status(sm_plan *plan, void *stream)
 {
     if (!plan) return sm_fail(SM_ERR_ARG, "sm_plan_status: plan is NULL");
     SM_TRY(use_device(plan->device));
     hipStream_t st = (hipStream_t)stream;
-    i32 flag = 0;
-    SM_HIP(hipMemcpyAsync(&flag, &plan->d_flags[0], sizeof(i32), hipMemcpyDeviceToHost, st));
-    SM_HIP(hipMemsetAsync(&plan->d_flags[0], 0, sizeof(i32), st));
-    SM_HIP(hipStreamSynchronize(st));
-    if (flag)
+    i32 f[4];
+    SM_TRY(read_flags(plan, st, 1, f));
+    if (f[0])
         return sm_fail(SM_ERR_ZERO_DIV, "contour interval is zero ((max-min)/lines == 0): the "
                        "reference divides by it");
     return SM_OK;

@@ -81,6 +81,7 @@ struct sm_plan {
     i32 *d_web_tmp;      // int32 map for narrow results of kernels without a narrow store path
     i32 *d_flags;        // [0] = zero-interval flag, [1] = has-zero scratch,
                          // [2] = edge table is not of threshold form
+    i32 *h_flags;        // pinned host copy of d_flags (k_publish_flags)
     u32 *d_edge_tab;     // 766 x {lo | hi << 16}: edge iff sb <= lo || sb >= hi
     double tab_threshold;  // threshold d_edge_tab was built for
     int tab_valid;

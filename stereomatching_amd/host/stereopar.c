@@ -133,6 +133,10 @@ static void algorithm(const uint8_t *first, const uint8_t *second, int width, in
 
     /* third step: draw contour lines */
     int in_tmp = 0;
+#ifdef NO_WRITES
+    /* nothing is dumped between the stages: queue all of step 3, synchronise once */
+    GPU(sm_step3(plan, web, tmp, params.times, params.lines_to_draw, 1, minmax, out, &in_tmp, NULL));
+#else
     GPU(sm_fill_web_holes(plan, web, tmp, params.times, 1, &in_tmp, NULL));
     int32_t *filled = in_tmp ? tmp : web;
     write_gpu_image(filled, width, height, 0, IMTYPE_GRAY_INT, make_filename("web", PROGRAM, 2));
@@ -140,6 +144,7 @@ static void algorithm(const uint8_t *first, const uint8_t *second, int width, in
     GPU(sm_draw_contour_map(plan, filled, minmax, params.lines_to_draw, 1, out, NULL));
     GPU(sm_plan_status(plan, NULL)); /* synchronises; reports a zero interval */
     write_gpu_image(out, width, height, 0, IMTYPE_BINARY, make_filename("output", PROGRAM, 0));
+#endif
 
     GPU(sm_stream_sync(0, NULL));
     double t2 = get_time();

@@ -1,0 +1,390 @@
+/*
+ * stereopar_batch.c -- `stereopar-batch`: a BATCH of independent stereo pairs
+ * over every visible GPU, plain C host code over the C ABI of
+ * include/stereo_hip.h.
+ *
+ * The reference processes one pair on one device (src/stereo.cu:350-409:
+ * main() reads two images, uploads them, runs algorithm() on device 0).  This
+ * program keeps that single-pair contract per pair -- same decoding, same
+ * parameters and validation, same stages up to the web map -- and adds what
+ * the reference does not have: pair j goes to device j mod n_devices (no
+ * exchange between devices: pairs are independent), each device has its own
+ * host thread, plan, streams and pinned staging buffers, and uploads, kernels
+ * and downloads of neighbouring batches overlap (two slots in flight per
+ * device).  Results come back as NARROW web maps (uint8 when the shifts fit,
+ * else uint16: sm_run_typed), a quarter / half of the int32 PCIe traffic.
+ *
+ *   stereopar-batch [options] LIST [threshold] [square_width]
+ *     LIST          text file, one pair per line: "left-image right-image"
+ *                   (8-bit gray PNG or binary PGM, all pairs the same size)
+ *     threshold, square_width   as for stereopar (defaults 0.15, 21)
+ *   options
+ *     -d 0,1,...    devices to use (default: $STEREO_DEVICES, else all visible)
+ *     -n SHIFTS     number of shifts (default: $STEREO_NUM_SHIFTS, else 30)
+ *     -g            ghost borders (stereopar-ghost semantics) instead of toroidal
+ *     -b PAIRS      pairs per launch (default 8)
+ *     -o DIR        write each web map to DIR/web-<index>.pgm (binary PGM, maxval =
+ *                   shifts; DIR must exist).  Default: no files (timing).
+ *     -r REPEAT     process the list REPEAT times (throughput measurements)
+ *
+ * stdout: one line
+ *   pairs = P, devices = K, width = W, height = H, shifts = D, elapsed = T, pairs_per_s = R, checksum = C
+ * where elapsed covers upload, kernels and download of all pairs (decoding is
+ * done before the clock starts, as the reference reads its images before t1)
+ * and checksum is the sum over all web pixels of all pairs (order-independent).
+ * Errors: message on stderr, exit code 1, as the reference's programs.
+ */
+#include "image.h"
+#include "stereo_hip.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#ifndef NUM_SHIFTS
+#define NUM_SHIFTS 30
+#endif
+#define DEFAULT_THRESHOLD 0.15
+#define DEFAULT_SQUARE_WIDTH 21
+#define MAX_DEVICES 64
+#define SLOTS 2
+
+typedef struct {
+    char *left, *right;
+    uint8_t *px[2];        /* decoded samples */
+} Pair;
+
+typedef struct {
+    /* job */
+    int device, n_devices, rank;      /* rank = position of this device in the device list */
+    Pair *pairs;
+    int n_pairs, repeat;
+    int width, height, num_shifts, square_width, border, batch;
+    double threshold;
+    const char *out_dir;
+    pthread_barrier_t *start;
+    /* result */
+    unsigned long long checksum;
+    int done_pairs;
+    int failed;
+    char error[512];
+} Worker;
+
+static double get_time(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + (double)ts.tv_nsec / 1e9;
+}
+
+static int parse_double(const char *s, double *n)   /* src/util.h:63-75 */
+{
+    char *end;
+    *n = strtod(s, &end);
+    return *n == 0 && end == s;
+}
+
+static int parse_int(const char *s, int *n)
+{
+    char *end;
+    *n = (int)strtol(s, &end, 0);
+    return *n == 0 && end == s;
+}
+
+static int fail(const char *message)
+{
+    fprintf(stderr, "%s\n", message);
+    return 1;
+}
+
+#define W_TRY(call)                                                        \
+    do {                                                                   \
+        if ((call) != SM_OK) {                                             \
+            snprintf(w->error, sizeof w->error, "%s", sm_last_error());    \
+            w->failed = 1;                                                 \
+            goto out;                                                      \
+        }                                                                  \
+    } while (0)
+
+static void write_pgm(const char *dir, int index, const void *web, int bytes, int width, int height,
+                      int maxval)
+{
+    char name[1200];
+    snprintf(name, sizeof name, "%s/web-%d.pgm", dir, index);
+    FILE *f = fopen(name, "wb");
+    if (!f)
+        return;                 /* like write_image: silently skip what cannot be opened */
+    fprintf(f, "P5\n%d %d\n%d\n", width, height, maxval);
+    const size_t n = (size_t)width * height;
+    if (bytes == 1) {
+        fwrite(web, 1, n, f);
+    } else {                    /* 16-bit PGM is big-endian */
+        const uint16_t *v = web;
+        for (size_t i = 0; i < n; i++) {
+            fputc(v[i] >> 8, f);
+            fputc(v[i] & 255, f);
+        }
+    }
+    fclose(f);
+}
+
+/* one device: its share of the pairs, two batches in flight */
+static void *worker_main(void *arg)
+{
+    Worker *w = arg;
+    const int dev = w->device;
+    const size_t n = (size_t)w->width * w->height;
+    const int web_type = w->num_shifts <= 255 ? SM_WEB_U8 : SM_WEB_U16;
+    const int web_bytes = web_type == SM_WEB_U8 ? 1 : 2;
+    sm_plan *plan[SLOTS] = {NULL};
+    void *stream[SLOTS] = {NULL};
+    uint8_t *h_in[SLOTS] = {NULL}, *d_in[SLOTS] = {NULL};
+    void *h_web[SLOTS] = {NULL}, *d_web[SLOTS] = {NULL};
+    int in_flight[SLOTS] = {0}, first_index[SLOTS] = {0};
+
+    /* this device's pairs: j with j mod n_devices == rank, over all repeats */
+    int mine = 0;
+    for (int j = w->rank; j < w->n_pairs; j += w->n_devices) mine++;
+    const long total = (long)mine * w->repeat;
+
+    /* allocation and set-up, before the clock starts (src/stereo.cu:296-308) */
+    for (int s = 0; s < SLOTS && !w->failed; s++) {
+        if (sm_plan_create(dev, w->width, w->height, w->num_shifts, w->square_width, w->border,
+                           w->batch, &plan[s]) ||
+            sm_plan_prepare_threshold(plan[s], w->threshold, NULL) ||
+            sm_stream_create(dev, &stream[s]) ||
+            sm_host_alloc(2 * n * w->batch, (void **)&h_in[s]) ||
+            sm_host_alloc(n * web_bytes * w->batch, &h_web[s]) ||
+            sm_malloc(dev, 2 * n * w->batch, (void **)&d_in[s]) ||
+            sm_malloc(dev, n * web_bytes * w->batch, &d_web[s])) {
+            snprintf(w->error, sizeof w->error, "%s", sm_last_error());
+            w->failed = 1;
+        }
+    }
+    pthread_barrier_wait(w->start);       /* main() takes t1 here */
+    if (w->failed)
+        goto out;
+
+    long next = 0;            /* index into this device's sequence of pairs */
+    int s = 0;
+    while (next < total || in_flight[0] || in_flight[1]) {
+        /* collect what this slot carried two submissions ago */
+        if (in_flight[s]) {
+            W_TRY(sm_stream_sync(dev, stream[s]));
+            for (int k = 0; k < in_flight[s]; k++) {
+                const uint8_t *m8 = (const uint8_t *)h_web[s] + (size_t)k * n * web_bytes;
+                unsigned long long sum = 0;
+                if (web_bytes == 1)
+                    for (size_t i = 0; i < n; i++) sum += m8[i];
+                else
+                    for (size_t i = 0; i < n; i++) sum += ((const uint16_t *)m8)[i];
+                w->checksum += sum;
+                const long seq = first_index[s] + k;                 /* in this device's sequence */
+                const int j = w->rank + (int)(seq % mine) * w->n_devices;   /* global pair index */
+                if (w->out_dir && seq < mine)
+                    write_pgm(w->out_dir, j, m8, web_bytes, w->width, w->height, w->num_shifts);
+                w->done_pairs++;
+            }
+            in_flight[s] = 0;
+        }
+        if (next < total) {
+            /* stage the next batch: lefts then rights, as sm_run expects a batch */
+            int b = 0;
+            for (; b < w->batch && next + b < total; b++) {
+                const int j = w->rank + (int)((next + b) % mine) * w->n_devices;
+                memcpy(h_in[s] + (size_t)b * n, w->pairs[j].px[0], n);
+            }
+            for (int k = 0; k < b; k++) {
+                const int j = w->rank + (int)((next + k) % mine) * w->n_devices;
+                memcpy(h_in[s] + (size_t)(b + k) * n, w->pairs[j].px[1], n);
+            }
+            W_TRY(sm_memcpy_h2d_async(dev, d_in[s], h_in[s], 2 * n * b, stream[s]));
+            W_TRY(sm_run_typed(plan[s], d_in[s], d_in[s] + (size_t)b * n, w->threshold, b, d_web[s],
+                               web_type, NULL, stream[s]));
+            W_TRY(sm_memcpy_d2h_async(dev, h_web[s], d_web[s], n * web_bytes * b, stream[s]));
+            in_flight[s] = b;
+            first_index[s] = (int)next;
+            next += b;
+        }
+        s ^= 1;
+    }
+out:
+    for (int k = 0; k < SLOTS; k++) {
+        if (stream[k]) { sm_stream_sync(dev, stream[k]); sm_stream_destroy(dev, stream[k]); }
+        if (plan[k]) sm_plan_destroy(plan[k]);
+        if (h_in[k]) sm_host_free(h_in[k]);
+        if (h_web[k]) sm_host_free(h_web[k]);
+        if (d_in[k]) sm_free(dev, d_in[k]);
+        if (d_web[k]) sm_free(dev, d_web[k]);
+    }
+    return NULL;
+}
+
+static int parse_devices(const char *list, int *devices, int visible)
+{
+    int n = 0;
+    char *copy = strdup(list), *save = NULL;
+    for (char *tok = strtok_r(copy, ",", &save); tok; tok = strtok_r(NULL, ",", &save)) {
+        int d;
+        if (parse_int(tok, &d) || d < 0 || d >= visible || n == MAX_DEVICES) {
+            free(copy);
+            return -1;
+        }
+        devices[n++] = d;
+    }
+    free(copy);
+    return n;
+}
+
+int main(int argc, char *argv[])
+{
+    const char *device_list = getenv("STEREO_DEVICES"), *out_dir = NULL;
+    int num_shifts = NUM_SHIFTS, border = SM_TOROIDAL, batch = 8, repeat = 1;
+    const char *env = getenv("STEREO_NUM_SHIFTS");
+    if (env && atoi(env) > 0)
+        num_shifts = atoi(env);
+
+    int a = 1;
+    for (; a < argc && argv[a][0] == '-' && argv[a][1]; a++) {
+        const char opt = argv[a][1];
+        if (opt == 'g') { border = SM_GHOST; continue; }
+        if (a + 1 >= argc || !strchr("dnbor", opt)) { a = argc; break; }
+        const char *val = argv[++a];
+        if (opt == 'd') device_list = val;
+        else if (opt == 'o') out_dir = val;
+        else {
+            int v;
+            if (parse_int(val, &v) || v < 1) {
+                fprintf(stderr, "error: -%c must be a positive number\n", opt);
+                return 1;
+            }
+            if (opt == 'n') num_shifts = v;
+            if (opt == 'b') batch = v;
+            if (opt == 'r') repeat = v;
+        }
+    }
+    if (a >= argc) {
+        fprintf(stderr, "usage: stereopar-batch [-d devices] [-n shifts] [-g] [-b pairs per launch] "
+                        "[-o dir] [-r repeat] [pair list] [threshold = %g] [square_width = %d]\n",
+                DEFAULT_THRESHOLD, DEFAULT_SQUARE_WIDTH);
+        return 1;
+    }
+    const char *list_name = argv[a++];
+    double threshold = DEFAULT_THRESHOLD;
+    int square_width = DEFAULT_SQUARE_WIDTH;
+    if (a < argc && parse_double(argv[a++], &threshold))
+        return fail("error: threshold must be a number");
+    if (a < argc && parse_int(argv[a++], &square_width))
+        return fail("error: square_width must be a number");
+    if (threshold < 0.0 || threshold > 1.0)
+        return fail("error: threshold must be between 0 and 1");
+    if (num_shifts > 65535)
+        return fail("error: the number of shifts must not exceed 65535");
+
+    /* the list */
+    FILE *lf = fopen(list_name, "r");
+    if (!lf) {
+        fprintf(stderr, "error reading pair list %s:", list_name);
+        perror("");
+        return 1;
+    }
+    Pair *pairs = NULL;
+    int n_pairs = 0, cap = 0;
+    char l[1024], r[1024], line[2200];
+    while (fgets(line, sizeof line, lf)) {
+        if (line[0] == '#' || line[0] == '\n')
+            continue;
+        if (sscanf(line, "%1023s %1023s", l, r) != 2) {
+            fprintf(stderr, "error: line %d of %s does not name two images\n", n_pairs + 1, list_name);
+            return 1;
+        }
+        if (n_pairs == cap) {
+            cap = cap ? 2 * cap : 64;
+            pairs = realloc(pairs, (size_t)cap * sizeof *pairs);
+            if (!pairs)
+                return fail("error: out of memory");
+        }
+        pairs[n_pairs].left = strdup(l);
+        pairs[n_pairs].right = strdup(r);
+        n_pairs++;
+    }
+    fclose(lf);
+    if (n_pairs == 0)
+        return fail("error: the pair list is empty");
+
+    /* decode (before the clock starts, as the reference reads its images before t1) */
+    int width = 0, height = 0;
+    for (int j = 0; j < n_pairs; j++) {
+        for (int side = 0; side < 2; side++) {
+            int wd, ht;
+            if (read_image_u8(side ? pairs[j].right : pairs[j].left, &pairs[j].px[side], &wd, &ht))
+                return 1;
+            if (j == 0 && side == 0) { width = wd; height = ht; }
+            if (wd != width || ht != height)
+                return fail("error: the two images must have equal width and height");
+        }
+    }
+    if (square_width > width || square_width > height)
+        return fail("error: square width must not be higher than image width/height");
+
+    /* devices */
+    int visible = 0;
+    if (sm_device_count(&visible) != SM_OK)
+        return fail(sm_last_error());
+    if (visible < 1)
+        return fail("error: no GPU visible");
+    int devices[MAX_DEVICES], n_devices = 0;
+    if (device_list && *device_list) {
+        n_devices = parse_devices(device_list, devices, visible);
+        if (n_devices < 1) {
+            fprintf(stderr, "error: device list \"%s\" is not a list of devices 0..%d\n", device_list, visible - 1);
+            return 1;
+        }
+    } else {
+        for (; n_devices < visible && n_devices < MAX_DEVICES; n_devices++) devices[n_devices] = n_devices;
+    }
+    if (n_devices > n_pairs)
+        n_devices = n_pairs;
+
+    Worker workers[MAX_DEVICES];
+    pthread_t threads[MAX_DEVICES];
+    memset(workers, 0, sizeof workers);
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, NULL, (unsigned)n_devices + 1);
+    for (int k = 0; k < n_devices; k++) {
+        Worker *w = &workers[k];
+        w->device = devices[k]; w->n_devices = n_devices; w->rank = k;
+        w->pairs = pairs; w->n_pairs = n_pairs; w->repeat = repeat;
+        w->width = width; w->height = height; w->num_shifts = num_shifts;
+        w->square_width = square_width; w->border = border; w->batch = batch;
+        w->threshold = threshold; w->out_dir = out_dir; w->start = &start;
+        if (pthread_create(&threads[k], NULL, worker_main, w))
+            return fail("error: cannot start a device thread");
+    }
+    pthread_barrier_wait(&start);         /* every device has its plans and buffers */
+    const double t1 = get_time();
+    unsigned long long checksum = 0;
+    int done = 0, failed = 0;
+    for (int k = 0; k < n_devices; k++) {
+        pthread_join(threads[k], NULL);
+        if (workers[k].failed) {
+            fprintf(stderr, "%s\n", workers[k].error);
+            failed = 1;
+        }
+        checksum += workers[k].checksum;
+        done += workers[k].done_pairs;
+    }
+    const double elapsed = get_time() - t1;
+    if (failed)
+        return 1;
+    printf("pairs = %d, devices = %d, width = %d, height = %d, shifts = %d, elapsed = %f, "
+           "pairs_per_s = %f, checksum = %llu\n",
+           done, n_devices, width, height, num_shifts, elapsed, done / elapsed, checksum);
+    for (int j = 0; j < n_pairs; j++) {
+        free(pairs[j].left); free(pairs[j].right); free(pairs[j].px[0]); free(pairs[j].px[1]);
+    }
+    free(pairs);
+    return 0;
+}

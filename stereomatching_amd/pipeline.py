@@ -225,6 +225,19 @@ class StereoPlan:
         check(lib.sm_plan_status(self._h, self._stream()))
         return out
 
+    def step3(self, web, times=DEFAULT_TIMES, num_lines=DEFAULT_LINES):
+        """fill_web_holes + min/max + draw_contour_map with a single synchronisation
+        (sm_step3) -> (hole-filled web, contour image, minmax)."""
+        web = self._images(web, torch.int32, "web").clone()
+        tmp = torch.empty_like(web)
+        pairs = web.shape[0]
+        mm = torch.empty((pairs, 2), dtype=torch.int32, device=self._dev)
+        out = self._new(pairs, torch.uint8)
+        which = C.c_int(0)
+        check(lib.sm_step3(self._h, _ptr(web), _ptr(tmp), int(times), int(num_lines), pairs, _ptr(mm),
+                           _ptr(out), C.byref(which), self._stream()))
+        return (tmp if which.value else web), out, mm
+
     # ---- the whole of algorithm() --------------------------------------------
     def algorithm(self, first, second, params: AlgorithmParams = AlgorithmParams(), step3=True):
         """Stage order of src/stereo.cu:289-347; returns the images the reference dumps

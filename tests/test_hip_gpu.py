@@ -284,7 +284,7 @@ def test_baseline_config_4k_full_image_vs_oracle(hip, cfg):
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 def test_baseline_config_c4_batch_full_size(hip, mode):
     """C4 as one GPU sees it: a batch of 8 x 1080p pairs, 64 shifts, 7x7, in ONE launch --
-    the 128-row tiles and the two-waves-per-SIMD kernel variant the batch geometry selects.
+    the tiling and the two-waves-per-SIMD kernel variant the batch geometry selects.
     All 8 maps, every pixel, against the oracle (toroidal is the configuration; the ghost
     border runs the same geometry)."""
     w, h, d, sw, _ = CONFIGS["C4"]
@@ -293,7 +293,8 @@ def test_baseline_config_c4_batch_full_size(hip, mode):
     left, right = np.stack(ls), np.stack(rs)
     plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
     g = plan.geometry()
-    assert g["kernel"] == 4 and g["tile_h"] >= 64, plan.describe()      # bit-sliced, tall tiles
+    assert g["kernel"] == 4 and g["two_wave_variant"] == 1, plan.describe()   # bit-sliced, CAP2
+    assert g["tiles_x"] * g["tiles_y"] * pairs <= 2048, plan.describe()        # one round of the chip
     web, best = plan.run(dev(left), dev(right), 0.15, want_best=True)
     web_h, best_h = host(web), host(best)
     for j in range(pairs):

@@ -52,7 +52,7 @@ int main()
     unsigned *out;
     (void)hipMalloc(&out, 256 * 4 * 4 * 64 * sizeof(unsigned));
     for (int w = 1; w <= 3; w++) {
-        run<1>(out, w); run<2>(out, w); run<3>(out, w); run<4>(out, w); run<8>(out, w);
+        run<1>(out, w); run<2>(out, w); run<3>(out, w); run<4>(out, w); run<5>(out, w); run<6>(out, w); run<8>(out, w); run<12>(out, w);
     }
     return 0;
 }

@@ -81,6 +81,28 @@ for rep in range(3):
     uniq, cnt = np.unique(simd_key, return_counts=True)
     print(f"  distinct CUs {len(np.unique(key))}, distinct SIMDs {len(uniq)}; waves per SIMD histogram:",
           dict(zip(*np.unique(cnt, return_counts=True))))
+    # the two waves of a SIMD: do they finish together?
+    order = np.argsort(simd_key, kind="stable")
+    sk, lf, st = simd_key[order], life[order], rt[order, 0]
+    pair = np.flatnonzero(sk[:-1] == sk[1:])
+    pair = pair[np.r_[True, np.diff(pair) > 1]] if len(pair) else pair
+    if len(pair):
+        a, b = lf[pair], lf[pair + 1]
+        fast, slow = np.minimum(a, b), np.maximum(a, b)
+        first_is_fast = np.where(st[pair] <= st[pair + 1], a <= b, b <= a)
+        print(f"  SIMD pairs {len(pair)}: faster wave median {np.median(fast):.1f} us, slower wave median "
+              f"{np.median(slow):.1f} us; pairs whose lifetimes differ by > 10 us: {int((slow - fast > 10).sum())}; "
+              f"earlier-started wave is the faster one in {100 * first_is_fast.mean():.0f} %")
+        print("  slower - faster (us) pct", q, np.percentile(slow - fast, q).round(1))
+    single = np.flatnonzero(np.isin(simd_key, uniq[cnt == 1]))
+    if len(single):
+        print(f"  waves alone on their SIMD: {len(single)}, lifetime median {np.median(life[single]):.1f} us")
+    # per CU: the spread of wave end times
+    cu_end = {}
+    for k_, e_ in zip(key, rt[:, 3]):
+        cu_end.setdefault(int(k_), []).append(e_)
+    last = np.array([max(v) for v in cu_end.values()])
+    print("  last wave end per CU (us) pct", q, np.percentile(last, q).round(1))
     # overlap: how many waves were alive on a SIMD at once (max), and second-round waves
     late = rt[:, 0] > 5.0
     print(f"  waves starting later than 5 us after the first: {int(late.sum())}"
