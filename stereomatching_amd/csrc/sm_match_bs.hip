@@ -225,6 +225,176 @@ __device__ __forceinline__ void addsub_planes(u32 (&s)[SB], const u32 (&hn)[HB],
     }
 }
 
+// ---------------------------------------------------------------------------
+// LOCKSTEP forms (SM_BS_LOCKSTEP).  Measured on gfx950 with exactly two waves per SIMD
+// (tools/ubench_issue.hip, tools/ubench_body.hip): a VALU instruction that reads the
+// result of the instruction issued 1 / 2 / 3 instructions earlier in its own wave costs
+// the SIMD 8 / 4 / ~2.7 issue cycles instead of 2, and the OLDER wave of the pair keeps
+// its full rate while the younger one is left with what remains (in the kernel: older
+// waves done after 74 us, younger after 107).  From a distance of 4 on the SIMD issues
+// one instruction every 2 cycles.  The compiler models VALU latency as 1 and lines
+// dependent instructions up back to back (13-17 % of this kernel's instructions had
+// distance 1, another 20-36 % distance 2).  So the arithmetic below is written as IT
+// independent items advanced side by side, operation by operation -- every dependency
+// then has a distance >= IT -- and each operation is followed by a scheduling barrier
+// (SM_PIN) so that the order written here is the order issued.
+// ---------------------------------------------------------------------------
+#ifndef SM_BS_LOCKSTEP
+#define SM_BS_LOCKSTEP 1
+#endif
+#define SM_PIN() __builtin_amdgcn_sched_barrier(0)
+// Re-phase the two waves of a SIMD.  Measured (tools/gen_ubench_bankrules.py, two waves per
+// SIMD): ONE half-rate VALU instruction (v_alignbit, DPP moves, v_bfe, v_perm, v_lshl_or,
+// v_and_or; v_lshlrev / v_mul_u32_u24 half as bad) leaves the pair in a state where the
+// older wave issues every 4 cycles and the younger only every 8 -- 2.67 cycles per
+// instruction for the SIMD instead of 2 -- and they STAY there until a scalar instruction
+// passes: 1 alignbit per 64 v_bitop3 costs 3.9 cycles per instruction, the same with an
+// s_nop behind each alignbit 2.7.  SM_SYNC(level) emits that s_nop where SM_BS_NOP >= level.
+#ifndef SM_BS_PRIO
+#define SM_BS_PRIO 0      // a STATIC priority only swaps which wave of the pair is starved (measured)
+#endif
+#ifndef SM_BS_SLICE
+#define SM_BS_SLICE 16    // swap every 65536 cycles (~31 us): 13 / 15 / 17 measured slower
+#endif
+#ifndef SM_BS_NOP
+#define SM_BS_NOP 2
+#endif
+#define SM_SYNC(level) do { if (SM_BS_NOP >= (level)) { asm volatile("s_nop 0"); SM_PIN(); } } while (0)
+#define BOP_ANDN 0x0C      // ~a & b
+#define BOP_ORN 0xCF       // ~a | b   (a ? b : all ones)
+#define BOP_XNOR 0xC3      // ~(a ^ b)            (c ignored)
+
+// IT counters side by side: inputs come from xin(item, i), made when first used
+template <int N, int HB, int IT, typename XF>
+__device__ __forceinline__ void count_lockstep(XF xin, u32 (&h)[IT][HB])
+{
+    u32 q[IT][2 * N + 2];      // wires of the current weight; [0, N) of weight 0 are the inputs
+    int head = 0, tail = N;
+#pragma unroll
+    for (int w = 0; w < HB; w++) {
+        u32 nx[IT][N + 1];     // carries: wires of the next weight
+        int nn = 0;
+#pragma unroll
+        for (int adder = 0; adder < N; adder++) {
+            if (tail - head >= 3) {
+                u32 a[IT], b[IT], c[IT];
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    const bool in0 = w == 0 && head < N, in1 = w == 0 && head + 1 < N, in2 = w == 0 && head + 2 < N;
+                    a[it] = in0 ? xin(it, in0 ? head : 0) : q[it][head];
+                    b[it] = in1 ? xin(it, in1 ? head + 1 : 0) : q[it][head + 1];
+                    c[it] = in2 ? xin(it, in2 ? head + 2 : 0) : q[it][head + 2];
+                }
+#pragma unroll
+                for (int it = 0; it < IT; it++) { q[it][tail] = bop<BOP_XOR3>(a[it], b[it], c[it]); SM_PIN(); }
+#pragma unroll
+                for (int it = 0; it < IT; it++) { nx[it][nn] = bop<BOP_MAJ>(a[it], b[it], c[it]); SM_PIN(); }
+                SM_SYNC(2);
+                head += 3; tail++; nn++;
+            }
+        }
+        if (tail - head == 2) {
+            u32 a[IT], b[IT];
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const bool in0 = w == 0 && head < N, in1 = w == 0 && head + 1 < N;
+                a[it] = in0 ? xin(it, in0 ? head : 0) : q[it][head];
+                b[it] = in1 ? xin(it, in1 ? head + 1 : 0) : q[it][head + 1];
+            }
+#pragma unroll
+            for (int it = 0; it < IT; it++) { q[it][tail] = a[it] ^ b[it]; SM_PIN(); }
+#pragma unroll
+            for (int it = 0; it < IT; it++) { nx[it][nn] = a[it] & b[it]; SM_PIN(); }
+            head += 2; tail++; nn++;
+        }
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const bool in0 = w == 0 && head < N;
+            h[it][w] = tail - head == 1 ? (in0 ? xin(it, in0 ? head : 0) : q[it][head]) : 0u;
+        }
+        head = 0; tail = 0;
+#pragma unroll
+        for (int i = 0; i < N + 1; i++)
+            if (i < nn) {
+#pragma unroll
+                for (int it = 0; it < IT; it++) q[it][tail] = nx[it][i];
+                tail++;
+            }
+    }
+}
+
+// S[dd0 + g] += h[g] for g < GS side by side (warm-up rows)
+template <int SB, int HB, int GS, int DS>
+__device__ __forceinline__ void add_lockstep(u32 (&S)[DS][SB], int dd0, const u32 (&h)[GS][HB])
+{
+    u32 c[GS];
+#pragma unroll
+    for (int g = 0; g < GS; g++) { c[g] = S[dd0 + g][0] & h[g][0]; SM_PIN(); }
+#pragma unroll
+    for (int g = 0; g < GS; g++) { S[dd0 + g][0] ^= h[g][0]; SM_PIN(); }
+#pragma unroll
+    for (int k = 1; k < SB; k++) {
+        u32 cn[GS];
+#pragma unroll
+        for (int g = 0; g < GS; g++) {
+            if (k + 1 < SB) { cn[g] = k < HB ? bop<BOP_MAJ>(S[dd0 + g][k], h[g][k], c[g]) : (S[dd0 + g][k] & c[g]); SM_PIN(); }
+            else cn[g] = 0;
+        }
+#pragma unroll
+        for (int g = 0; g < GS; g++) {
+            if (k < HB) S[dd0 + g][k] = bop<BOP_XOR3>(S[dd0 + g][k], h[g][k], c[g]);
+            else S[dd0 + g][k] ^= c[g];
+            SM_PIN();
+        }
+#pragma unroll
+        for (int g = 0; g < GS; g++) c[g] = cn[g];
+        SM_SYNC(3);
+    }
+}
+
+// S[dd0 + g] += hn[g] - ho[g] for g < GS side by side: the HB-plane differences in two's
+// complement (sign = borrow out), then one ripple add of the sign-extended differences
+template <int SB, int HB, int GS, int DS>
+__device__ __forceinline__ void addsub_lockstep(u32 (&S)[DS][SB], int dd0, const u32 (&hn)[GS][HB],
+                                                const u32 (&ho)[GS][HB])
+{
+    u32 dl[GS][HB], b[GS];
+#pragma unroll
+    for (int g = 0; g < GS; g++) { b[g] = bop<BOP_ANDN>(hn[g][0], ho[g][0], 0u); SM_PIN(); }
+#pragma unroll
+    for (int g = 0; g < GS; g++) { dl[g][0] = hn[g][0] ^ ho[g][0]; SM_PIN(); }
+#pragma unroll
+    for (int k = 1; k < HB; k++) {
+#pragma unroll
+        for (int g = 0; g < GS; g++) { dl[g][k] = bop<BOP_XOR3>(hn[g][k], ho[g][k], b[g]); SM_PIN(); }
+#pragma unroll
+        for (int g = 0; g < GS; g++) { b[g] = bop<BOP_BORROW>(hn[g][k], ho[g][k], b[g]); SM_PIN(); }
+        SM_SYNC(3);
+    }
+    u32 c[GS];
+#pragma unroll
+    for (int g = 0; g < GS; g++) { c[g] = S[dd0 + g][0] & dl[g][0]; SM_PIN(); }
+#pragma unroll
+    for (int g = 0; g < GS; g++) { S[dd0 + g][0] ^= dl[g][0]; SM_PIN(); }
+#pragma unroll
+    for (int k = 1; k < SB; k++) {
+        u32 cn[GS];
+#pragma unroll
+        for (int g = 0; g < GS; g++) {
+            const u32 a = k < HB ? dl[g][k] : b[g];
+            if (k + 1 < SB) { cn[g] = bop<BOP_MAJ>(S[dd0 + g][k], a, c[g]); SM_PIN(); } else cn[g] = 0;
+        }
+#pragma unroll
+        for (int g = 0; g < GS; g++) {
+            const u32 a = k < HB ? dl[g][k] : b[g];
+            S[dd0 + g][k] = bop<BOP_XOR3>(S[dd0 + g][k], a, c[g]); SM_PIN();
+        }
+#pragma unroll
+        for (int g = 0; g < GS; g++) c[g] = cn[g];
+        SM_SYNC(3);
+    }
+}
+
 template <int CTRL>
 __device__ __forceinline__ u32 dpp(u32 v)
 {
@@ -276,6 +446,26 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     const int tid = threadIdx.x;
     const int pair = blockIdx.z;
     SM_STAMP(0);
+#if SM_BS_PRIO
+    // Unequal priorities for the waves that share a SIMD.  With equal priority the SIMD's
+    // arbiter serves the OLDEST wave first, and once any half-rate instruction (v_alignbit,
+    // DPP, v_bfe, ...) has passed, the younger wave gets an issue slot only every 8 cycles
+    // while the older keeps its 4 (tools/gen_ubench_bankrules.py, "mix 16": 4.0 cycles per
+    // instruction for the SIMD; with a raised priority on the odd hardware wave slots 2.5;
+    // this kernel: older waves done after 74 us, younger after 107).  The hardware wave
+    // slot (HW_ID bits 3:0) tells the co-resident waves apart: slot parity -> priority.
+    if (__builtin_amdgcn_s_getreg(63492) & 1) __builtin_amdgcn_s_setprio(SM_BS_PRIO);
+#endif
+#if SM_BS_SLICE
+    // Time-sliced priority: the wave whose hardware slot parity equals bit SM_BS_SLICE of
+    // the shader clock runs at raised priority, the other at 0, and the roles swap every
+    // 2^SM_BS_SLICE cycles -- both read the same clock, so exactly one of a pair is
+    // favoured at any time.  The SIMD serves its favoured wave at the rate of a wave alone
+    // and gives the other what is left (measured: 4.9 vs 9.0 cycles per instruction here);
+    // without the swap the favoured wave finishes a third earlier and the SIMD then runs
+    // half empty until the other is done.
+    const unsigned slot_parity = __builtin_amdgcn_s_getreg(63492) & 1;
+#endif
     int tile_x, tile_y;
     sm_xcd_tile(g.tiles_x, g.tiles_y, tile_x, tile_y);
     const int tx0 = tile_x * g.tw;
@@ -369,6 +559,66 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
         count_bits<N, HB>(x, h);
     };
 
+#if SM_BS_LOCKSTEP
+    constexpr int GW = DS >= 4 ? 4 : DS;      // shifts side by side in a warm-up row
+    constexpr int GS = 2;                     // ... in a steady-state row (2 x {row in, row out})
+    static_assert(DS % GW == 0 && DS % GS == 0, "shift groups");
+    // warm-up: one window row into all sums, GW shifts side by side
+    auto slide_in = [&](int srow) {
+        RowViews v;
+        load_views(srow, v);
+        u32 rv[N + GW - 1];                   // right views dd0 ... dd0 + GW + N - 2 of the group
+#pragma unroll
+        for (int m = 0; m < N - 1; m++) rv[m + GW] = rview(v, m);
+#pragma unroll
+        for (int dd0 = 0; dd0 < DS; dd0 += GW) {
+#pragma unroll
+            for (int m = 0; m < N - 1; m++) rv[m] = rv[m + GW];
+#pragma unroll
+            for (int m = 0; m < GW; m++) { rv[N - 1 + m] = rview(v, dd0 + N - 1 + m); SM_PIN(); }
+            SM_SYNC(1);
+            u32 h[GW][HB];
+            count_lockstep<N, HB, GW>([&](int it, int i) -> u32 {
+                const u32 x = GHOST ? bop<BOP_XOR_AND>(v.lv[i], rv[it + i], cvv[i]) : (v.lv[i] ^ rv[it + i]);
+                SM_PIN();
+                return x;
+            }, h);
+            add_lockstep<SB, HB, GW, DS>(S, dd0, h);
+        }
+    };
+    // steady state: one row in and one row out, GS shifts x {in, out} side by side
+    auto slide_views = [&](const RowViews &vn, const RowViews &vo) {
+        u32 rn[N + GS - 1], ro[N + GS - 1];
+#pragma unroll
+        for (int m = 0; m < N - 1; m++) { rn[m + GS] = rview(vn, m); ro[m + GS] = rview(vo, m); }
+#pragma unroll
+        for (int dd0 = 0; dd0 < DS; dd0 += GS) {
+#pragma unroll
+            for (int m = 0; m < N - 1; m++) { rn[m] = rn[m + GS]; ro[m] = ro[m + GS]; }
+#pragma unroll
+            for (int m = 0; m < GS; m++) {
+                rn[N - 1 + m] = rview(vn, dd0 + N - 1 + m); SM_PIN();
+                ro[N - 1 + m] = rview(vo, dd0 + N - 1 + m); SM_PIN();
+            }
+            SM_SYNC(1);
+            u32 h[2 * GS][HB];                // item 2g = shift dd0 + g row in, 2g + 1 = row out
+            count_lockstep<N, HB, 2 * GS>([&](int it, int i) -> u32 {
+                const u32 l = (it & 1) ? vo.lv[i] : vn.lv[i];
+                const u32 r = (it & 1) ? ro[(it >> 1) + i] : rn[(it >> 1) + i];
+                const u32 x = GHOST ? bop<BOP_XOR_AND>(l, r, cvv[i]) : (l ^ r);
+                SM_PIN();
+                return x;
+            }, h);
+            u32 hn[GS][HB], ho[GS][HB];
+#pragma unroll
+            for (int gq = 0; gq < GS; gq++)
+#pragma unroll
+                for (int k = 0; k < HB; k++) { hn[gq][k] = h[2 * gq][k]; ho[gq][k] = h[2 * gq + 1][k]; }
+            addsub_lockstep<SB, HB, GS, DS>(S, dd0, hn, ho);
+            SM_SYNC(2);
+        }
+    };
+#else
     // warm-up: one window row into all sums
     auto slide_in = [&](int srow) {
         RowViews v;
@@ -403,6 +653,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
             addsub_planes<SB, HB>(S[dd], hn, ho);
         }
     };
+#endif
 #if !SM_BS_PREFETCH
     auto slide_both = [&](int srow_new, int srow_old) {
         RowViews vn, vo;
@@ -423,7 +674,15 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     // register allocator met two definitions of every sum plane at the join and paid
     // 16 x SB register copies per row for it).
 #pragma unroll 1
-    for (int e = 0; e < N; e++) slide_in(e);
+    for (int e = 0; e < N; e++) {
+#if SM_BS_SLICE
+        if ((((unsigned)(__builtin_amdgcn_s_memtime() >> SM_BS_SLICE)) ^ slot_parity) & 1)
+            __builtin_amdgcn_s_setprio(3);
+        else
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        slide_in(e);
+    }
     SM_STAMP(2);
 
 #if SM_BS_PREFETCH
@@ -442,6 +701,12 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
 #endif
 #pragma unroll 1
     for (int t = 0;;) {
+#if SM_BS_SLICE
+        if ((((unsigned)(__builtin_amdgcn_s_memtime() >> SM_BS_SLICE)) ^ slot_parity) & 1)
+            __builtin_amdgcn_s_setprio(3);
+        else
+            __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- winner-take-all of output row t over this lane's 16 shifts
         const int y = ty0 + t;
 #if SM_BS_PREFETCH
@@ -457,9 +722,110 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
 
         u32 B[SB], arg[ABMAX];
 #pragma unroll
-        for (int k = 0; k < SB; k++) B[k] = 0xffffffffu;
-#pragma unroll
         for (int k = 0; k < ABMAX; k++) arg[k] = 0;
+#if SM_BS_LOCKSTEP
+        {
+            // Four independent scans side by side, one per quarter of the lane's shifts
+            // (ascending, <=: the last of equal counts wins), then the quarters are merged
+            // pairwise -- the higher quarter wins ties -- which is the same winner as one
+            // scan over all shifts.
+            constexpr int Q = 4, QS = DS / Q;          // shifts per quarter
+            constexpr int AQ = AB - 2;                 // planes of the index within a quarter
+            u32 Bq[Q][SB], aq[Q][AQ > 0 ? AQ : 1];
+#pragma unroll
+            for (int i = 0; i < QS; i++) {
+                u32 upd[Q];
+                u32 rcd[Q];
+#pragma unroll
+                for (int qd = 0; qd < Q; qd++) {
+                    const int dd = qd * QS + i;
+                    rcd[qd] = dd ? alignbit(rc1, rc0, dd) : rc0; SM_PIN();
+                }
+                SM_SYNC(1);
+                if (i == 0) {
+                    // first shift of a quarter: it wins wherever its centre pixel matches
+#pragma unroll
+                    for (int qd = 0; qd < Q; qd++) {
+                        upd[qd] = bop<BOP_XNOR>(lc, rcd[qd], 0u); SM_PIN();
+                        if (!FULLD) { upd[qd] &= (u32)__builtin_amdgcn_sbfe((int)dvalid, qd * QS + i, 1); SM_PIN(); }
+                    }
+#pragma unroll
+                    for (int k = 0; k < SB; k++)
+#pragma unroll
+                        for (int qd = 0; qd < Q; qd++) { Bq[qd][k] = bop<BOP_ORN>(upd[qd], S[qd * QS + i][k], 0u); SM_PIN(); }
+#pragma unroll
+                    for (int a = 0; a < AQ; a++)
+#pragma unroll
+                        for (int qd = 0; qd < Q; qd++) aq[qd][a] = 0;
+                } else {
+                    u32 bw[Q];
+#pragma unroll
+                    for (int k = 0; k < SB; k++)
+#pragma unroll
+                        for (int qd = 0; qd < Q; qd++) {
+                            bw[qd] = bop<BOP_BORROW>(Bq[qd][k], S[qd * QS + i][k], k ? bw[qd] : 0u); SM_PIN();
+                            if (qd == Q - 1 && (k & 1)) SM_SYNC(3);
+                        }
+#pragma unroll
+                    for (int qd = 0; qd < Q; qd++) {
+                        upd[qd] = bop<BOP_UPD>(lc, rcd[qd], bw[qd]); SM_PIN();
+                        if (!FULLD) { upd[qd] &= (u32)__builtin_amdgcn_sbfe((int)dvalid, qd * QS + i, 1); SM_PIN(); }
+                    }
+#pragma unroll
+                    for (int k = 0; k < SB; k++)
+#pragma unroll
+                        for (int qd = 0; qd < Q; qd++) {
+                            Bq[qd][k] = bop<BOP_SEL>(upd[qd], S[qd * QS + i][k], Bq[qd][k]); SM_PIN();
+                            if (qd == Q - 1 && (k & 1)) SM_SYNC(3);
+                        }
+#pragma unroll
+                    for (int a = 0; a < AQ; a++)
+#pragma unroll
+                        for (int qd = 0; qd < Q; qd++) {
+                            if ((i >> a) & 1) aq[qd][a] |= upd[qd]; else aq[qd][a] = bop<BOP_ANDN>(upd[qd], aq[qd][a], 0u);
+                            SM_PIN();
+                        }
+                }
+            }
+            // quarters 0|1 and 2|3 side by side: take the higher one iff its count is <=
+            u32 bwm[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < SB; k++)
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    // borrow of lower - higher: 1 <=> lower < higher
+                    bwm[m] = bop<BOP_BORROW>(Bq[2 * m][k], Bq[2 * m + 1][k], k ? bwm[m] : 0u); SM_PIN();
+                }
+            // halves: the selects of one plane feed the final comparison of that plane
+            u32 Bh[2][SB], ah[2][AQ + 1];
+            u32 bwf = 0;
+#pragma unroll
+            for (int k = 0; k < SB; k++) {
+#pragma unroll
+                for (int m = 0; m < 2; m++) { Bh[m][k] = bop<BOP_SEL>(bwm[m], Bq[2 * m][k], Bq[2 * m + 1][k]); SM_PIN(); }
+                if (k < AQ) {
+#pragma unroll
+                    for (int m = 0; m < 2; m++) { ah[m][k] = bop<BOP_SEL>(bwm[m], aq[2 * m][k], aq[2 * m + 1][k]); SM_PIN(); }
+                }
+                if (k > 0) { bwf = bop<BOP_BORROW>(Bh[0][k - 1], Bh[1][k - 1], k > 1 ? bwf : 0u); SM_PIN(); }
+            }
+#pragma unroll
+            for (int k = SB; k < AQ; k++)
+#pragma unroll
+                for (int m = 0; m < 2; m++) { ah[m][k] = bop<BOP_SEL>(bwm[m], aq[2 * m][k], aq[2 * m + 1][k]); SM_PIN(); }
+            ah[0][AQ] = ~bwm[0]; SM_PIN();             // index bit AQ: the higher quarter was taken
+            ah[1][AQ] = ~bwm[1]; SM_PIN();
+            bwf = bop<BOP_BORROW>(Bh[0][SB - 1], Bh[1][SB - 1], SB > 1 ? bwf : 0u); SM_PIN();
+            // bwf = 1 <=> lower half < higher half: keep the lower one
+#pragma unroll
+            for (int k = 0; k < SB; k++) { B[k] = bop<BOP_SEL>(bwf, Bh[0][k], Bh[1][k]); SM_PIN(); }
+#pragma unroll
+            for (int k = 0; k <= AQ; k++) { arg[k] = bop<BOP_SEL>(bwf, ah[0][k], ah[1][k]); SM_PIN(); }
+            arg[AQ + 1] = ~bwf; SM_PIN();
+        }
+#else
+#pragma unroll
+        for (int k = 0; k < SB; k++) B[k] = 0xffffffffu;
 #pragma unroll
         for (int dd = 0; dd < DS; dd++) {
             const u32 rcd = dd ? alignbit(rc1, rc0, dd) : rc0;
@@ -475,6 +841,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
                 if ((dd >> k) & 1) arg[k] |= upd; else arg[k] &= ~upd;
             }
         }
+#endif
 
         // ---- merge the nl lanes of this word: lower count wins, on a tie the lane
         // with the higher shifts (partner's bit K of the lane index set)
@@ -483,6 +850,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
             u32 pb[SB], pa[AB + K];                                                    \
             _Pragma("unroll") for (int k = 0; k < SB; k++) pb[k] = from_partner<K>(B[k]);      \
             _Pragma("unroll") for (int k = 0; k < AB + K; k++) pa[k] = from_partner<K>(arg[k]); \
+            SM_PIN(); SM_SYNC(1);                                                      \
             const u32 mine_high = (s >> K) & 1 ? 0xffffffffu : 0u;                     \
             u32 bw = mine_high;          /* borrow-in 1: partner - mine - 1 < 0 <=> partner <= mine */ \
             bw = ~bw;                    /* partner is the high one iff I am not */   \
@@ -591,6 +959,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
         }
 
         // ---- slide the window down: staged row t + N - 1 in, staged row t - 1 out
+        SM_SYNC(1);
         if (++t >= rows_out) break;
 #if SM_BS_PREFETCH
         {
@@ -605,6 +974,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
                 lds_issue(qn, aNewL, aNewR);
                 lds_issue(qo, aNewL - sL * N, aNewR - sR * N);
             }
+            SM_PIN(); SM_SYNC(1);
             slide_views(vn, vo);
         }
 #else

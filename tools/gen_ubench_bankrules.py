@@ -13,12 +13,13 @@ def reg_in_bank(bank, k):
     return 16 + ((bank - 16) % 4) + 4 * (k % 46)
 
 def body(kind):
+    kind = kind.replace(" +skew", "").replace(" +prio", "").replace(" +far", "")
     out = []
     for i in range(N):
         d = 8 + (i % 8)
         b0 = d % 4
         k = i // 8
-        if kind == "b3 distinct":
+        if kind == "b3 distinct" or kind.startswith("skew "):
             s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
         elif kind == "b3 s1=s0bank":
             s1, s2 = reg_in_bank(b0, k), reg_in_bank(b0 + 2, k)
@@ -49,6 +50,109 @@ def body(kind):
             out.append(f"v_alignbit_b32 v{d}, v{d}, v{reg_in_bank(b0, k)}, 7"); continue
         elif kind == "alignbit vshift":
             out.append(f"v_alignbit_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}, v{reg_in_bank(b0 + 2, k)}"); continue
+        elif kind.startswith("dist "):
+            c = int(kind.split()[1])
+            d = 8 + (i % c)
+            b0 = d % 4
+            out.append(f"v_bitop3_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}, v{reg_in_bank(b0 + 2, k)} bitop3:0x96"); continue
+        elif kind.startswith("mix "):
+            # every m-th instruction is a half-rate v_alignbit, 8 chains
+            m = int(kind.split()[1])
+            if i % m == m - 1:
+                out.append(f"v_alignbit_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}, 7"); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind.startswith("burst "):
+            # the first b instructions of every 256 are half-rate v_alignbit, the rest full rate
+            b = int(kind.split()[1])
+            if i % 256 < b:
+                out.append(f"v_alignbit_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}, 7"); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind.startswith("hr "):
+            # every 16th instruction is the named half-rate candidate
+            m = kind.split()[1]
+            if i % 16 == 15:
+                r1 = reg_in_bank(b0 + 1, k)
+                op = {"lshl": f"v_lshlrev_b32 v{d}, 3, v{d}", "lshr": f"v_lshrrev_b32 v{d}, 3, v{d}",
+                      "mul24": f"v_mul_u32_u24 v{d}, v{d}, v{r1}", "bfe": f"v_bfe_u32 v{d}, v{d}, 3, 9",
+                      "dpp": f"v_mov_b32_dpp v{d}, v{r1} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf",
+                      "mov": f"v_mov_b32 v{d}, v{r1}", "add": f"v_add_u32 v{d}, v{d}, v{r1}",
+                      "lshlor": f"v_lshl_or_b32 v{d}, v{d}, 3, v{r1}", "andor": f"v_and_or_b32 v{d}, v{d}, v{r1}, v{r1}",
+                      "cndmask": f"v_cndmask_b32 v{d}, v{d}, v{r1}, vcc", "readlane": f"v_readfirstlane_b32 s30, v{d}",
+                      "perm": f"v_perm_b32 v{d}, v{d}, v{r1}, v{r1}"}[m]
+                out.append(op); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind.startswith("after "):
+            # a half-rate v_alignbit every m instructions, followed by a candidate re-phasing instruction
+            _, m, what = kind.split()
+            m = int(m)
+            if i % m == m - 2:
+                out.append(f"v_alignbit_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}, 7"); continue
+            if i % m == m - 1:
+                out.append({"branch": "s_branch 0", "nop": "s_nop 0", "nop7": "s_nop 7", "sleep1": "s_sleep 1",
+                            "cbranch": "s_cbranch_vccz 0", "setpc": "s_nop 0", "barrier": "s_barrier",
+                            "waitcnt": "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)"}[what]); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind.startswith("burstb "):
+            # b alignbits, then a re-phasing instruction, then full-rate code; period 512
+            _, b, what = kind.split()
+            b = int(b)
+            if i % 512 < b:
+                out.append(f"v_alignbit_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}, 7"); continue
+            if i % 512 == b:
+                out.append({"branch": "s_branch 0", "nop": "s_nop 0", "sleep1": "s_sleep 1", "none": "v_nop"}[what]); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind.startswith("fix "):
+            # a half-rate v_alignbit every 64 instructions, FOLLOWED by a candidate re-sync instruction
+            m = kind.split()[1]
+            if i % 64 == 62:
+                out.append(f"v_alignbit_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}, 7"); continue
+            if i % 64 == 63:
+                out.append({"snop0": "s_nop 0", "snop3": "s_nop 3", "setprio": "s_setprio 0", "vnop": "v_nop",
+                            "sadd": "s_add_u32 s30, s30, 1", "waitcnt": "s_waitcnt lgkmcnt(15)",
+                            "smov": "s_mov_b32 s30, 0", "sleep": "s_sleep 0"}[m]); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind.startswith("dst "):
+            # destinations rotate over many registers (never read); sources from v16..v99
+            m = kind.split()[1]
+            srcs = list(range(16, 100))
+            a, b, c = srcs[(3 * i) % 84], srcs[(3 * i + 1) % 84], srcs[(3 * i + 2) % 84]
+            if m == "rot64":
+                dd_ = 100 + (i % 64)
+            elif m == "bank0":
+                dd_ = 100 + 4 * (i % 16)
+            elif m == "rot64mix":      # plus a half-rate alignbit every 16th
+                dd_ = 100 + (i % 64)
+                if i % 16 == 15:
+                    out.append(f"v_alignbit_b32 v{dd_}, v{a}, v{b}, 7"); continue
+            elif m == "inplace3":      # dst = one of the sources, all different registers each time
+                dd_ = a
+                out.append(f"v_bitop3_b32 v{dd_}, v{a}, v{b}, v{c} bitop3:0x96"); continue
+            out.append(f"v_bitop3_b32 v{dd_}, v{a}, v{b}, v{c} bitop3:0x96"); continue
+        elif kind == "xormix":
+            # alternate 8-byte v_bitop3 and 4-byte v_xor
+            if i % 2:
+                out.append(f"v_xor_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}"); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind.startswith("nopevery "):
+            m = int(kind.split()[1])
+            if i % m == m - 1:
+                out.append("s_nop 0"); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind == "ldswait":
+            if i % 256 == 100:
+                out.append("ds_read_b32 v200, v201"); continue
+            if i % 256 == 110:
+                out.append("s_waitcnt lgkmcnt(0)"); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind.startswith("rare "):
+            # ONE half-rate instruction per body of N (position 0), the rest full rate
+            m = kind.split()[1]
+            if i == 0:
+                op = {"alignbit": f"v_alignbit_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}, 7",
+                      "nop": "s_nop 0", "sleep": "s_sleep 1",
+                      }[m]
+                out.append(op); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
         elif kind == "mov_dpp":
             out.append(f"v_mov_b32_dpp v{d}, v{reg_in_bank(b0 + 1, k)} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); continue
         else:
@@ -56,16 +160,30 @@ def body(kind):
         out.append(f"v_bitop3_b32 v{d}, v{d}, v{s1}, v{s2} bitop3:0x96")
     return "\\n".join(out)
 
-kinds = ["b3 distinct", "b3 s1=s0bank", "b3 s2=s0bank", "b3 s1=s2bank", "b3 all same", "b3 s1==s2 reg",
-         "b3 s1==s0 reg", "b3 dst other", "xor distinct", "xor same bank", "xor e64 distinct",
-         "alignbit distinct", "alignbit same bank", "alignbit vshift", "mov_dpp"]
+kinds = ["b3 distinct +skew", "mix 64 +skew", "after 64 branch +skew", "after 64 nop +skew", "after 64 nop7 +skew",
+         "after 64 sleep1 +skew", "after 64 waitcnt +skew", "after 16 branch +skew", "after 16 nop +skew",
+         "burstb 16 none +skew", "burstb 16 branch +skew", "burstb 16 nop +skew", "burstb 16 sleep1 +skew",
+         "burstb 64 branch +skew", "burstb 64 sleep1 +skew"]
 src = ['// GENERATED by tools/gen_ubench_bankrules.py -- do not edit', '#include <hip/hip_runtime.h>',
        '#include <cstdio>', '#include <vector>', '#include <map>', '#include <algorithm>', '']
-clob = ", ".join(f'"v{i}"' for i in range(8, 201))
+clob = ", ".join(f'"v{i}"' for i in range(8, 202)) + ', "vcc", "s30"'
 for k, kind in enumerate(kinds):
     src.append(f'__global__ __launch_bounds__(64) void k{k}(unsigned *out, unsigned long long *info, int iters)\n{{')
     src.append('    unsigned seed = threadIdx.x * 2654435761u + blockIdx.x;')
     src.append('    asm volatile("' + "\\n".join(f"v_mov_b32 v{i}, %0" for i in range(8, 200)) + f'" :: "v"(seed) : {clob});')
+    if kind.endswith(" +prio"):
+        src.append('    if (__builtin_amdgcn_s_getreg(63492) & 1) asm volatile("s_setprio 3");')
+    if kind.endswith(" +far"):
+        src.append('    if (__builtin_amdgcn_s_getreg(63492) & 1) {   // odd slot: half a body ahead')
+        half = "\\n".join(body(kind).split("\\n")[:N // 2])
+        src.append(f'        asm volatile("{half}" ::: {clob});')
+        src.append('    }')
+    if kind.startswith("skew ") or kind.endswith(" +skew"):
+        n_extra = int(kind.split()[1]) if kind.startswith("skew ") else 37
+        src.append('    if (__builtin_amdgcn_s_getreg(63492) & 1) {   // odd hardware wave slot: run ahead / behind')
+        src.append('        asm volatile("' + "\\n".join("v_bitop3_b32 v8, v8, v17, v18 bitop3:0x96" for _ in range(n_extra)) + f'" ::: {clob});')
+        src.append('    }')
+    src.append('    asm volatile("v_mov_b32 v201, 0" ::: "v201", "v200");')
     src.append('    const unsigned long long t0 = __builtin_amdgcn_s_memtime();')
     src.append('    for (int it = 0; it < iters; it++)')
     src.append(f'        asm volatile("{body(kind)}" ::: {clob});')
@@ -106,6 +224,7 @@ static void run(kern_t k, const char *name, int n, unsigned *out, unsigned long 
 int main()
 {
     unsigned *out; unsigned long long *info;
+    setvbuf(stdout, NULL, _IOLBF, 0);
     (void)hipMalloc(&out, 2048 * 64 * 4); (void)hipMalloc(&info, 2048 * 3 * 8);
 ''')
 for k, kind in enumerate(kinds):

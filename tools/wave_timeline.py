@@ -81,6 +81,8 @@ for rep in range(3):
     uniq, cnt = np.unique(simd_key, return_counts=True)
     print(f"  distinct CUs {len(np.unique(key))}, distinct SIMDs {len(uniq)}; waves per SIMD histogram:",
           dict(zip(*np.unique(cnt, return_counts=True))))
+    slot = hwid & 0xf
+    print("  hardware wave slots in use:", dict(zip(*np.unique(slot, return_counts=True))))
     # the two waves of a SIMD: do they finish together?
     order = np.argsort(simd_key, kind="stable")
     sk, lf, st = simd_key[order], life[order], rt[order, 0]
@@ -94,6 +96,15 @@ for rep in range(3):
               f"{np.median(slow):.1f} us; pairs whose lifetimes differ by > 10 us: {int((slow - fast > 10).sum())}; "
               f"earlier-started wave is the faster one in {100 * first_is_fast.mean():.0f} %")
         print("  slower - faster (us) pct", q, np.percentile(slow - fast, q).round(1))
+        # phases of the earlier-started ("older") and the later-started wave of each pair
+        rto, cko = rt[order], ck[order]
+        first = np.where(st[pair] <= st[pair + 1], pair, pair + 1)
+        second = np.where(st[pair] <= st[pair + 1], pair + 1, pair)
+        for name, idx in (("older", first), ("younger", second)):
+            ph_us = [np.median(rto[idx, k + 1] - rto[idx, k]) for k in range(3)]
+            ph_cy = [np.median(cko[idx, k + 1] - cko[idx, k]) for k in range(3)]
+            print(f"    {name:8s} wave: stage {ph_us[0]:6.2f} us / warm-up {ph_us[1]:6.2f} us ({ph_cy[1]:9.0f} cyc)"
+                  f" / rows {ph_us[2]:6.2f} us ({ph_cy[2]:9.0f} cyc)")
     single = np.flatnonzero(np.isin(simd_key, uniq[cnt == 1]))
     if len(single):
         print(f"  waves alone on their SIMD: {len(single)}, lifetime median {np.median(life[single]):.1f} us")
