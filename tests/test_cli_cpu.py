@@ -182,3 +182,25 @@ def test_cli_errors_match_the_reference_contract(programs, tmp_path, prog):
     p = run(exe, "rgb.png", "b.pgm", cwd=tmp_path)
     assert p.returncode == 1
     assert p.stderr == "error reading image rgb.png: wrong number of channels (3) (image must be grayscale)"
+
+
+def test_stereopar_batch_argument_errors(programs, tmp_path):  # noqa: F811
+    """argv / list validation of the batch host happens before any GPU call"""
+    exe = programs["timing"]["stereopar"].parent / "stereopar-batch"
+    p = run(exe, cwd=tmp_path)
+    assert p.returncode == 1 and p.stderr.startswith("usage: stereopar-batch")
+    p = run(exe, "nolist.txt", cwd=tmp_path)
+    assert p.returncode == 1 and "error reading pair list nolist.txt:" in p.stderr
+    (tmp_path / "empty.txt").write_text("# nothing\n")
+    p = run(exe, "empty.txt", cwd=tmp_path)
+    assert p.returncode == 1 and "the pair list is empty" in p.stderr
+    (tmp_path / "bad.txt").write_text("only-one-name\n")
+    p = run(exe, "bad.txt", cwd=tmp_path)
+    assert p.returncode == 1 and "does not name two images" in p.stderr
+    (tmp_path / "missing.txt").write_text("a.pgm b.pgm\n")
+    p = run(exe, "missing.txt", cwd=tmp_path)
+    assert p.returncode == 1 and "error reading image a.pgm:" in p.stderr
+    p = run(exe, "-b", "0", "missing.txt", cwd=tmp_path)
+    assert p.returncode == 1 and "-b must be a positive number" in p.stderr
+    p = run(exe, "missing.txt", "2.0", cwd=tmp_path)
+    assert p.returncode == 1     # image error comes first, as in the reference's argument order

@@ -678,3 +678,75 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["bound"] == "valu"
     assert out["roofline"]["kernel_launches_timed"] >= 6
     assert "gather_ms" in out
+
+
+# ---------------------------------------------------------------------------
+# narrow web maps (sm_match_wta_typed / sm_run_typed) and the fused step 3
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("w,h,d,sw,dtype", [
+    (300, 150, 128, 9, torch.uint8),      # bit-sliced kernel, dword stores of 4 pixels
+    (300, 150, 128, 9, torch.uint16),
+    (257, 61, 64, 7, torch.uint8),        # width not a multiple of 4: scalar stores
+    (130, 70, 300, 5, torch.uint16),      # more shifts than a byte holds
+    (120, 80, 30, 23, torch.uint8),       # popcount kernel: int32 map + narrowing pass
+    (60, 50, 30, 27, torch.uint16),       # generic kernel
+])
+def test_narrow_web_maps_equal_the_int32_map(hip, mode, w, h, d, sw, dtype):
+    le, re = rand_edges(w, h, seed=w + d)
+    plan = hip.StereoPlan(w, h, d, sw, mode)
+    plan.load_edges(dev(le), dev(re))
+    web32, best32 = plan.match_wta(1, want_best=True)
+    webn, bestn = plan.match_wta(1, want_best=True, web_dtype=dtype)
+    torch.cuda.synchronize()
+    _, oweb = oracle.hot_path(le, re, d, sw, mode)
+    assert np.array_equal(host(web32)[0], oweb), plan.describe()
+    assert np.array_equal(host(webn.to(torch.int32))[0], oweb), plan.describe()
+    assert torch.equal(best32, bestn)
+    plan.close()
+
+
+def test_narrow_web_rejects_too_many_shifts(hip):
+    plan = hip.StereoPlan(64, 48, 300, 5, "toroidal")
+    le, re = rand_edges(64, 48, 2)
+    plan.load_edges(dev(le), dev(re))
+    with pytest.raises(hip.capi.StereoHipError):
+        plan.match_wta(1, want_best=False, web_dtype=torch.uint8)
+    plan.close()
+
+
+@pytest.mark.parametrize("times,lines", [(32, 10), (3, 4), (0, 7)])
+def test_step3_in_one_sync_equals_the_staged_calls(hip, times, lines):
+    w, h, d, sw = 160, 90, 30, 9
+    left, right = make_pair(w, h, d, seed=21)
+    plan = hip.StereoPlan(w, h, d, sw, "toroidal", max_pairs=2)
+    web, _ = plan.run(dev(np.stack([left, left])), dev(np.stack([right, right])), 0.15)
+    # (a) a web from the hot path: no zero pixel, hole filling is the identity
+    filled, out, mm = plan.step3(web, times, lines)
+    want_f = plan.fill_web_holes(web, times)
+    want_o = plan.draw_contour_map(want_f, lines)
+    assert torch.equal(filled, want_f) and torch.equal(out, want_o)
+    assert torch.equal(mm, plan.image_min_max(want_f))
+    # (b) a web WITH holes takes the staged route inside sm_step3
+    holes = web.clone()
+    holes[:, 10:30, 20:60] = 0
+    holes[:, 0, :] = 0
+    filled, out, mm = plan.step3(holes, times, lines)
+    want_f = plan.fill_web_holes(holes, times)
+    want_o = plan.draw_contour_map(want_f, lines)
+    assert torch.equal(filled, want_f) and torch.equal(out, want_o)
+    for j in range(2):
+        assert np.array_equal(host(filled)[j], oracle.fill_web_holes(host(holes)[j], times))
+        assert np.array_equal(host(out)[j], oracle.draw_contour_map(host(filled)[j], lines))
+    plan.close()
+
+
+def test_step3_reports_a_zero_interval(hip):
+    plan = hip.StereoPlan(64, 48, 30, 5, "toroidal")
+    web = torch.full((1, 48, 64), 7, dtype=torch.int32, device="cuda")
+    with pytest.raises(hip.capi.StereoHipError) as e:
+        plan.step3(web, 4, 10)
+    assert e.value.code == hip.capi.SM_ERR_ZERO_DIV
+    plan.step3(torch.arange(48 * 64, dtype=torch.int32, device="cuda").view(1, 48, 64) + 1, 4, 10)  # flag cleared
+    plan.close()

@@ -2,10 +2,15 @@
 """End-to-end (PCIe-inclusive) throughput through the C ABI alone: pairs start in
 pinned host memory, results end in pinned host memory.  Three streams' worth of
 work are kept in flight (upload of pair k+1, kernels of pair k, download of pair
-k-1) with per-slot buffers.  This is NOT bench.py's `value` (which is measured
-with resident inputs); DESIGN.md quotes it next to it.
+k-1) with per-slot buffers and plans.  This is NOT bench.py's `value` (which is
+measured with resident inputs); bench.py --e2e reports it as an extra object and
+DESIGN.md quotes it next to the resident number.
 
     python tools/e2e_bench.py [C3] [pairs=24] [slots=3]
+
+Measured for the reference's int32 web map (sm_run) and for the narrow map
+(sm_run_typed: uint8 when the shifts fit, else uint16), which moves 4x / 2x fewer
+bytes back over PCIe.
 """
 import ctypes as C
 import sys
@@ -15,65 +20,96 @@ from pathlib import Path
 import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from stereomatching_amd.capi import check, lib  # noqa: E402
-from stereomatching_amd.synth import CONFIGS, make_pair  # noqa: E402
 
-cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
-npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-slots = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-w, h, d, sw, mode = CONFIGS[cfg]
-n = w * h
 vp = C.c_void_p
 
 
-def hostbuf(nbytes):
-    p = vp()
-    check(lib.sm_host_alloc(nbytes, C.byref(p)))
-    return p
+def measure_one(cfg: str, device: int, web_type: int, npairs: int = 24, slots: int = 3) -> dict:
+    from stereomatching_amd.capi import SM_WEB_I32, SM_WEB_U8, check, lib
+    from stereomatching_amd.synth import CONFIGS, make_pair
+
+    w, h, d, sw, mode = CONFIGS[cfg]
+    n = w * h
+    wb = 4 if web_type == SM_WEB_I32 else (1 if web_type == SM_WEB_U8 else 2)
+
+    def hostbuf(nbytes):
+        p = vp()
+        check(lib.sm_host_alloc(nbytes, C.byref(p)))
+        return p
+
+    def devbuf(nbytes):
+        p = vp()
+        check(lib.sm_malloc(device, nbytes, C.byref(p)))
+        return p
+
+    left, right = make_pair(w, h, d, seed=3)
+    S = []
+    for i in range(slots):
+        s = dict(hl=hostbuf(n), hr=hostbuf(n), hw=hostbuf(wb * n), dl=devbuf(n), dr=devbuf(n),
+                 dw=devbuf(wb * n), st=vp(), plan=vp())
+        C.memmove(s["hl"], left.ctypes.data, n)
+        C.memmove(s["hr"], right.ctypes.data, n)
+        check(lib.sm_stream_create(device, C.byref(s["st"])))
+        check(lib.sm_plan_create(device, w, h, d, sw, 1 if mode == "ghost" else 0, 1, C.byref(s["plan"])))
+        S.append(s)
+
+    def submit(s):
+        st = s["st"]
+        check(lib.sm_memcpy_h2d_async(device, s["dl"], s["hl"], n, st))
+        check(lib.sm_memcpy_h2d_async(device, s["dr"], s["hr"], n, st))
+        check(lib.sm_run_typed(s["plan"], s["dl"], s["dr"], 0.15, 1, s["dw"], web_type, None, st))
+        check(lib.sm_memcpy_d2h_async(device, s["hw"], s["dw"], wb * n, st))
+
+    for s in S:                      # warm-up
+        submit(s)
+    for s in S:
+        check(lib.sm_stream_sync(device, s["st"]))
+    t0 = time.perf_counter()
+    for k in range(npairs):
+        s = S[k % slots]
+        if k >= slots:
+            check(lib.sm_stream_sync(device, s["st"]))    # the slot's previous pair has fully landed
+        submit(s)
+    for s in S:
+        check(lib.sm_stream_sync(device, s["st"]))
+    dt = time.perf_counter() - t0
+    ctype = {4: C.c_int32, 2: C.c_uint16, 1: C.c_uint8}[wb]
+    web = np.ctypeslib.as_array(C.cast(S[0]["hw"], C.POINTER(ctype)), (h, w))
+    assert web.min() >= 1 and web.max() <= d
+    for s in S:
+        lib.sm_plan_destroy(s["plan"])
+        for k in ("dl", "dr", "dw"):
+            check(lib.sm_free(device, s[k]))
+        for k in ("hl", "hr", "hw"):
+            check(lib.sm_host_free(s[k]))
+        check(lib.sm_stream_destroy(device, s["st"]))
+    mb = (2 * n + wb * n) / 1e6
+    return {
+        "web_dtype": {4: "int32", 2: "uint16", 1: "uint8"}[wb],
+        "ms_per_pair": round(dt / npairs * 1e3, 4),
+        "Mpixel_disparities_per_s": round(w * h * d * npairs / dt / 1e6, 1),
+        "pcie_GBps": round(mb * npairs / dt / 1e3, 2),
+        "bytes_per_pair": {"in": 2 * n, "out": wb * n},
+        "pairs": npairs, "slots_in_flight": slots,
+    }
 
 
-def devbuf(nbytes):
-    p = vp()
-    check(lib.sm_malloc(0, nbytes, C.byref(p)))
-    return p
+def measure(cfg: str = "C3", device: int = 0, npairs: int = 24) -> dict:
+    """PCIe-inclusive rates for the reference's int32 map and for the narrow map."""
+    from stereomatching_amd.capi import SM_WEB_I32, SM_WEB_U8, SM_WEB_U16
+    from stereomatching_amd.synth import CONFIGS
+    d = CONFIGS[cfg][2]
+    return {
+        "what": "uint8 pairs from pinned host memory -> web maps in pinned host memory, C ABI only "
+                "(sm_memcpy_*_async + sm_run_typed), never part of `value`",
+        "config": cfg,
+        "int32": measure_one(cfg, device, SM_WEB_I32, npairs),
+        "narrow": measure_one(cfg, device, SM_WEB_U8 if d <= 255 else SM_WEB_U16, npairs),
+    }
 
 
-left, right = make_pair(w, h, d, seed=3)
-S = []
-for i in range(slots):
-    s = dict(hl=hostbuf(n), hr=hostbuf(n), hw=hostbuf(4 * n), dl=devbuf(n), dr=devbuf(n), dw=devbuf(4 * n),
-             st=vp(), plan=vp())
-    C.memmove(s["hl"], left.ctypes.data, n)
-    C.memmove(s["hr"], right.ctypes.data, n)
-    check(lib.sm_stream_create(0, C.byref(s["st"])))
-    check(lib.sm_plan_create(0, w, h, d, sw, 1 if mode == "ghost" else 0, 1, C.byref(s["plan"])))
-    S.append(s)
-
-
-def submit(s):
-    st = s["st"]
-    check(lib.sm_memcpy_h2d_async(0, s["dl"], s["hl"], n, st))
-    check(lib.sm_memcpy_h2d_async(0, s["dr"], s["hr"], n, st))
-    check(lib.sm_run(s["plan"], s["dl"], s["dr"], 0.15, 1, s["dw"], None, st))
-    check(lib.sm_memcpy_d2h_async(0, s["hw"], s["dw"], 4 * n, st))
-
-
-for s in S:                      # warm-up
-    submit(s)
-for s in S:
-    check(lib.sm_stream_sync(0, s["st"]))
-t0 = time.perf_counter()
-for k in range(npairs):
-    s = S[k % slots]
-    if k >= slots:
-        check(lib.sm_stream_sync(0, s["st"]))    # the slot's previous pair has fully landed
-    submit(s)
-for s in S:
-    check(lib.sm_stream_sync(0, s["st"]))
-dt = time.perf_counter() - t0
-web = np.ctypeslib.as_array(C.cast(S[0]["hw"], C.POINTER(C.c_int32)), (h, w))
-assert web.min() >= 1 and web.max() <= d
-mb = (2 * n + 4 * n) / 1e6
-print(f"{cfg}: {npairs} pairs through {slots} slots: {dt / npairs * 1e3:.3f} ms/pair end to end, "
-      f"{w * h * d * npairs / dt / 1e6:.0f} Mpixel-disparities/s, {mb * npairs / dt / 1e3:.1f} GB/s over PCIe "
-      f"({2 * n / 1e6:.1f} MB in + {4 * n / 1e6:.1f} MB out per pair)")
+if __name__ == "__main__":
+    import json
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+    npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+    print(json.dumps(measure(cfg, 0, npairs)))
