@@ -552,44 +552,34 @@ __global__ void k_count_zeros(const i32 *__restrict__ a, long long total, i32 *_
     if (__ballot(z) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
-__global__ void k_minmax_init(i32 *__restrict__ mm, int pairs)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < pairs) { mm[2 * i] = INT_MAX; mm[2 * i + 1] = INT_MIN; }
-}
-
-__global__ __launch_bounds__(256) void k_minmax(const i32 *__restrict__ a, long long n,
-                                                i32 *__restrict__ mm)
-{
-    const size_t base = (size_t)blockIdx.y * n;
-    i32 lo = INT_MAX, hi = INT_MIN;
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
-         p += (long long)gridDim.x * blockDim.x) {
-        const i32 v = a[base + p];
-        lo = min(lo, v);
-        hi = max(hi, v);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        lo = min(lo, __shfl_xor(lo, off));
-        hi = max(hi, __shfl_xor(hi, off));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&mm[2 * blockIdx.y], lo);
-        atomicMax(&mm[2 * blockIdx.y + 1], hi);
-    }
-}
-
 // min / max of each pair's image AND "some pixel is 0" (the hole-fill stage only ever
-// changes pixels that are 0), in one pass over the maps
+// changes pixels that are 0), in one pass over the maps.  HBM-bound: 16-byte loads where
+// the image allows, one atomic pair per WORKGROUP (atomics on one address serialise at
+// ~12 ns each: one pair per wave of a 2048-block grid cost 190 us at 4K)
 __global__ __launch_bounds__(256) void k_minmax_zero(const i32 *__restrict__ a, long long n,
                                                      i32 *__restrict__ mm, i32 *__restrict__ zero_flag)
 {
-    const size_t base = (size_t)blockIdx.y * n;
+    __shared__ i32 s_lo[4], s_hi[4], s_z[4];
+    const i32 *img = a + (size_t)blockIdx.y * n;
     i32 lo = INT_MAX, hi = INT_MIN;
     bool z = false;
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
-         p += (long long)gridDim.x * blockDim.x) {
-        const i32 v = a[base + p];
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long done = 0;
+    if ((((uintptr_t)img) & 15) == 0) {
+        typedef int v4i_ __attribute__((ext_vector_type(4)));
+        const v4i_ *q = reinterpret_cast<const v4i_ *>(img);
+        const long long nq = n >> 2;
+        for (long long p = tid; p < nq; p += stride) {
+            const v4i_ v = q[p];
+            lo = min(min(lo, v.x), min(v.y, min(v.z, v.w)));
+            hi = max(max(hi, v.x), max(v.y, max(v.z, v.w)));
+            z |= v.x == 0 || v.y == 0 || v.z == 0 || v.w == 0;
+        }
+        done = nq << 2;
+    }
+    for (long long p = done + tid; p < n; p += stride) {
+        const i32 v = img[p];
         lo = min(lo, v);
         hi = max(hi, v);
         z |= v == 0;
@@ -599,11 +589,25 @@ __global__ __launch_bounds__(256) void k_minmax_zero(const i32 *__restrict__ a, 
         hi = max(hi, __shfl_xor(hi, off));
     }
     const bool any_z = __ballot(z) != 0;
-    if ((threadIdx.x & 63) == 0) {
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_lo[wv] = lo; s_hi[wv] = hi; s_z[wv] = any_z; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        bool zz = false;
+        for (int k = 0; k < nw; k++) { lo = min(lo, s_lo[k]); hi = max(hi, s_hi[k]); zz |= s_z[k] != 0; }
         atomicMin(&mm[2 * blockIdx.y], lo);
         atomicMax(&mm[2 * blockIdx.y + 1], hi);
-        if (any_z) atomicOr(zero_flag, 1);
+        if (zz && zero_flag) atomicOr(zero_flag, 1);
     }
+}
+
+// {INT_MAX, INT_MIN} per pair, and the "has a zero pixel" flag cleared
+__global__ void k_step3_init(i32 *__restrict__ mm, int pairs, i32 *__restrict__ zero_flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pairs) { mm[2 * i] = INT_MAX; mm[2 * i + 1] = INT_MIN; }
+    if (i == 0 && zero_flag) *zero_flag = 0;
 }
 
 // hand the plan's flags to the host: one lane copies them into pinned host memory the
@@ -814,13 +818,16 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
         const bool gh = border == SM_GHOST;
         const void *fns[] = {
             (const void *)k_edge_thresholds, (const void *)k_pack_ext, (const void *)k_debug_planes,
-            (const void *)k_fill_holes_step, (const void *)k_count_zeros, (const void *)k_minmax_init,
-            (const void *)k_minmax, (const void *)k_contour, (const void *)k_minmax_zero,
-            (const void *)k_publish_flags,
+            (const void *)k_fill_holes_step, (const void *)k_count_zeros, (const void *)k_step3_init,
+            (const void *)k_contour, (const void *)k_minmax_zero, (const void *)k_publish_flags,
             gh ? (const void *)k_edges_ext4<true, true> : (const void *)k_edges_ext4<false, true>,
             gh ? (const void *)k_edges_ext<true, true> : (const void *)k_edges_ext<false, true>,
         };
         for (const void *f : fns) (void)hipFuncGetAttributes(&fa, f);
+    }
+    if (p->kernel == SM_KERNEL_BS) {
+        rc = sm_bs_prepare(p);
+        if (rc) { sm_plan_destroy(p); return rc; }
     }
     *out = p;
     return SM_OK;
@@ -1245,6 +1252,15 @@ extern "C" int sm_fill_web_holes(sm_plan *plan, int32_t *d_web, int32_t *d_tmp, 
     return run_sweeps(plan, d_web, d_tmp, times, pairs, result_in_tmp, st);
 }
 
+// one workgroup of 4 waves per 64 K pixels, at most 1024 of them per pair: enough loads in
+// flight to stream from HBM, few enough atomics
+static dim3 minmax_grid(long long n, int pairs)
+{
+    long long blocks = (n + 65535) / 65536;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    return dim3((unsigned)blocks, pairs);
+}
+
 extern "C" int sm_min_max(sm_plan *plan, const int32_t *d_image, int pairs, int32_t *d_minmax,
                           void *stream)
 {
@@ -1253,11 +1269,10 @@ extern "C" int sm_min_max(sm_plan *plan, const int32_t *d_image, int pairs, int3
     SM_TRY(use_device(plan->device));
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)plan->width * plan->height;
-    hipLaunchKernelGGL(k_minmax_init, dim3((pairs + 63) / 64), dim3(64), 0, st, d_minmax, pairs);
-    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
-    hipLaunchKernelGGL(k_minmax, dim3(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), pairs),
-                       dim3(256), 0, st, d_image, n, d_minmax);
-    SM_LAUNCH_CHECK("k_minmax");
+    hipLaunchKernelGGL(k_step3_init, dim3((pairs + 63) / 64), dim3(64), 0, st, d_minmax, pairs, (i32 *)nullptr);
+    hipLaunchKernelGGL(k_minmax_zero, minmax_grid(n, pairs), dim3(256), 0, st, d_image, n, d_minmax,
+                       (i32 *)nullptr);
+    SM_LAUNCH_CHECK("k_minmax_zero");
     return SM_OK;
 }
 
@@ -1303,16 +1318,14 @@ extern "C" int sm_step3(sm_plan *plan, int32_t *d_web, int32_t *d_tmp, int times
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)plan->width * plan->height;
     *result_in_tmp = 0;
-    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
-    const dim3 mm_grid(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), pairs);
+    const dim3 mm_grid = minmax_grid(n, pairs);
     const dim3 px_grid((unsigned)((n + 255) / 256), pairs);
 
     // Speculate that the map has no zero pixel (a web from the hot path never has: a
     // winning shift is stored as shift + 1): then hole filling is the identity, the
     // min/max pass over the unfilled map is the one the contour stage needs, and ONE
     // pass also proves the speculation.  Everything is queued before the only sync.
-    SM_HIP(hipMemsetAsync(&plan->d_flags[1], 0, sizeof(i32), st));
-    hipLaunchKernelGGL(k_minmax_init, dim3((pairs + 63) / 64), dim3(64), 0, st, d_minmax, pairs);
+    hipLaunchKernelGGL(k_step3_init, dim3((pairs + 63) / 64), dim3(64), 0, st, d_minmax, pairs, &plan->d_flags[1]);
     hipLaunchKernelGGL(k_minmax_zero, mm_grid, dim3(256), 0, st, d_web, n, d_minmax, &plan->d_flags[1]);
     hipLaunchKernelGGL(k_contour, px_grid, dim3(256), 0, st, d_web, d_minmax, num_lines, n, d_out,
                        plan->d_flags);
@@ -1323,8 +1336,8 @@ extern "C" int sm_step3(sm_plan *plan, int32_t *d_web, int32_t *d_tmp, int times
         // there ARE holes: do it the long way (sweeps, then min/max and contour again)
         SM_TRY(run_sweeps(plan, d_web, d_tmp, times, pairs, result_in_tmp, st));
         const i32 *filled = *result_in_tmp ? d_tmp : d_web;
-        hipLaunchKernelGGL(k_minmax_init, dim3((pairs + 63) / 64), dim3(64), 0, st, d_minmax, pairs);
-        hipLaunchKernelGGL(k_minmax, mm_grid, dim3(256), 0, st, filled, n, d_minmax);
+        hipLaunchKernelGGL(k_step3_init, dim3((pairs + 63) / 64), dim3(64), 0, st, d_minmax, pairs, (i32 *)nullptr);
+        hipLaunchKernelGGL(k_minmax_zero, mm_grid, dim3(256), 0, st, filled, n, d_minmax, (i32 *)nullptr);
         hipLaunchKernelGGL(k_contour, px_grid, dim3(256), 0, st, filled, d_minmax, num_lines, n, d_out,
                            plan->d_flags);
         SM_LAUNCH_CHECK("k_contour");

@@ -134,6 +134,7 @@ int sm_fail(int code, const char *fmt, ...);
 const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost, bool cap2);
 int sm_bs_default_ds(int n);
 int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);
+int sm_bs_prepare(sm_plan *plan);        // set-up launch: code object loaded before the first real one
 
 // sm_match.hip
 int sm_match_configure(sm_plan *plan);   // fills plan->kernel / plan->g

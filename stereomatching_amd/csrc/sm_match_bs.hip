@@ -443,6 +443,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
 
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     if (CAP2) asm volatile("" ::: "v175");
+    if (web == nullptr) return;     // the plan's set-up launch: loads the code object, does nothing
     const int tid = threadIdx.x;
     const int pair = blockIdx.z;
     SM_STAMP(0);
@@ -1039,6 +1040,23 @@ int sm_bs_default_ds(int n)
     if (sm_bs_kernel_ptr(n, 16, true, false, false)) return 16;
     if (sm_bs_kernel_ptr(n, 8, true, false, false)) return 8;
     return 0;
+}
+
+// One launch of the plan's kernel that does nothing (web == nullptr): the runtime loads a
+// code object when a kernel of it is first LAUNCHED -- this translation unit's is ~2 MB and
+// the first real launch otherwise waits ~130 us for it inside the caller's timed region.
+int sm_bs_prepare(sm_plan *plan)
+{
+    const MatchGeom &g = plan->g;
+    const void *fn = sm_bs_kernel_ptr(g.n, g.ds, g.nl * g.ds == g.D, plan->border == SM_GHOST, g.cap2 != 0);
+    if (!fn) return SM_OK;
+    i32 *none = nullptr;
+    void *args[] = {(void *)&plan->d_ext, (void *)&none, (void *)&none, (void *)&g};
+    hipError_t e = hipLaunchKernel(fn, dim3(1, 1, 1), dim3(g.threads), args, g.lds_bytes, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess)
+        return sm_fail(SM_ERR_HIP, "set-up launch of k_match_bs failed: %s", hipGetErrorString(e));
+    return SM_OK;
 }
 
 int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
