@@ -257,7 +257,7 @@ __device__ __forceinline__ void addsub_planes(u32 (&s)[SB], const u32 (&hn)[HB],
 #define SM_BS_SLICE 16    // swap every 65536 cycles (~31 us): 13 / 15 / 17 measured slower
 #endif
 #ifndef SM_BS_NOP
-#define SM_BS_NOP 2
+#define SM_BS_NOP 3
 #endif
 #define SM_SYNC(level) do { if (SM_BS_NOP >= (level)) { asm volatile("s_nop 0"); SM_PIN(); } } while (0)
 #define BOP_ANDN 0x0C      // ~a & b
@@ -466,6 +466,18 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     // without the swap the favoured wave finishes a third earlier and the SIMD then runs
     // half empty until the other is done.
     const unsigned slot_parity = __builtin_amdgcn_s_getreg(63492) & 1;
+    // the clock is read one row ahead of its use (s_memtime is a scalar memory read: its
+    // value takes ~100 cycles to arrive, and a wave that uses it at once waits that long)
+    unsigned long long clk = __builtin_amdgcn_s_memtime();
+#define SM_SLICE_PRIO()                                                               \
+    do {                                                                              \
+        if ((((unsigned)(clk >> SM_BS_SLICE)) ^ slot_parity) & 1) __builtin_amdgcn_s_setprio(3); \
+        else __builtin_amdgcn_s_setprio(0);                                           \
+    } while (0)
+#define SM_SLICE_READ() do { clk = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SM_SLICE_PRIO() do { } while (0)
+#define SM_SLICE_READ() do { } while (0)
 #endif
     int tile_x, tile_y;
     sm_xcd_tile(g.tiles_x, g.tiles_y, tile_x, tile_y);
@@ -675,15 +687,9 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     // register allocator met two definitions of every sum plane at the join and paid
     // 16 x SB register copies per row for it).
 #pragma unroll 1
-    for (int e = 0; e < N; e++) {
-#if SM_BS_SLICE
-        if ((((unsigned)(__builtin_amdgcn_s_memtime() >> SM_BS_SLICE)) ^ slot_parity) & 1)
-            __builtin_amdgcn_s_setprio(3);
-        else
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        slide_in(e);
-    }
+    SM_SLICE_PRIO();                // the warm-up rows are shorter than one time slice
+    for (int e = 0; e < N; e++) slide_in(e);
+    SM_SLICE_READ();
     SM_STAMP(2);
 
 #if SM_BS_PREFETCH
@@ -702,12 +708,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
 #endif
 #pragma unroll 1
     for (int t = 0;;) {
-#if SM_BS_SLICE
-        if ((((unsigned)(__builtin_amdgcn_s_memtime() >> SM_BS_SLICE)) ^ slot_parity) & 1)
-            __builtin_amdgcn_s_setprio(3);
-        else
-            __builtin_amdgcn_s_setprio(0);
-#endif
+        SM_SLICE_PRIO();
         // ---- winner-take-all of output row t over this lane's 16 shifts
         const int y = ty0 + t;
 #if SM_BS_PREFETCH
@@ -975,6 +976,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
                 lds_issue(qn, aNewL, aNewR);
                 lds_issue(qo, aNewL - sL * N, aNewR - sR * N);
             }
+            SM_SLICE_READ();         // behind the reads above: it is waited for with them, a row later
             SM_PIN(); SM_SYNC(1);
             slide_views(vn, vo);
         }
