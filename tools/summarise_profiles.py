@@ -16,17 +16,45 @@ src, dst = Path(sys.argv[1]), Path(sys.argv[2])
 key = sys.argv[3] if len(sys.argv) > 3 else "C3:1"
 dst.mkdir(parents=True, exist_ok=True)
 
-for f in glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")):
-    shutil.copy(f, dst / "kernel_stats.csv")
+def newest(pattern):
+    fs = sorted(glob.glob(pattern), key=lambda f: Path(f).stat().st_mtime)
+    return fs[-1:] if fs else []
+
+
+# rocprofv3 --stats summary as written, plus the same statistics recomputed from the kernel
+# trace WITHOUT the plan's set-up launch of the match kernel (one workgroup, ~2 us: it would
+# pull the average down)
+for f in newest(str(src / "kt" / "*" / "*_kernel_stats.csv")):
+    shutil.copy(f, dst / "kernel_stats_rocprof.csv")
+for f in newest(str(src / "kt" / "*" / "*_kernel_trace.csv")):
+    rows = list(csv.DictReader(open(f)))
+    by = collections.defaultdict(list)
+    for r in rows:
+        gs = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        by[r["Kernel_Name"]].append((gs, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    tot = sum(d for v in by.values() for _, d in v)
+    with open(dst / "kernel_stats.csv", "w") as out:
+        out.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","GridSize"\n')
+        for name, v in sorted(by.items(), key=lambda kv: -sum(d for _, d in kv[1])):
+            g = max(gs for gs, _ in v)
+            ds = [d for gs, d in v if gs == g]           # full-size dispatches only
+            out.write(f'"{name}",{len(ds)},{sum(ds)},{sum(ds) / len(ds):.1f},{100 * sum(ds) / tot:.2f},{min(ds)},{max(ds)},{g}\n')
 bench = [l for l in (src / "bench.json").read_text().splitlines() if l.startswith("{")]
 if bench:
     (dst / "bench.json").write_text(bench[-1] + "\n")
 
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(str(src / "pmc_*" / "*" / "*_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        counters[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for d in sorted(glob.glob(str(src / "pmc_*"))):
+    for f in newest(str(Path(d) / "*" / "*_counter_collection.csv")):
+        rows = list(csv.DictReader(open(f)))
+        biggest = collections.defaultdict(int)
+        for r in rows:
+            biggest[r["Kernel_Name"]] = max(biggest[r["Kernel_Name"]], int(r["Grid_Size"]))
+        for r in rows:
+            if int(r["Grid_Size"]) != biggest[r["Kernel_Name"]]:
+                continue                                  # the plan's one-workgroup set-up launch
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            counters[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in counters.items()
            if not k.startswith("__amd")}
 (dst / "pmc_summary.json").write_text(json.dumps(summary, indent=1, sort_keys=True) + "\n")
