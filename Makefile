@@ -39,7 +39,7 @@ $(O):
 	mkdir -p $@
 
 $(DEVLIB): $(KERNELS) stereomatching_amd/csrc/sm_internal.h include/stereo_hip.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize \
 	    -Iinclude -Istereomatching_amd/csrc $(KERNELS) -o $@
 
 $(O)/image.o: $(HOSTDIR)/image.c include/image.h | $(O)

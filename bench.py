@@ -183,7 +183,10 @@ def main():
     from stereomatching_amd import shard
     from stereomatching_amd.synth import CONFIGS, make_pair
 
-    rank, local_rank, world = shard.init("gloo" if rehearsal else None)
+    # SM_BENCH_NCCL_SELFTEST=1: create the RCCL process group even for one rank, so that a
+    # 1-GPU box runs the broadcast / barrier / all-reduce / gather calls of the N > 1 path
+    selftest = os.environ.get("SM_BENCH_NCCL_SELFTEST") == "1"
+    rank, local_rank, world = shard.init("gloo" if rehearsal else None, force=selftest)
     if rehearsal:
         local_rank = 0
     if world != args.gpus:
@@ -297,7 +300,7 @@ def main():
     value = units_per_step * world * args.steps / elapsed / 1e6
 
     gather_ms = None
-    if args.gather and world > 1:
+    if args.gather and (world > 1 or selftest):
         torch.cuda.synchronize(dev)
         shard.barrier()
         g0 = time.perf_counter()

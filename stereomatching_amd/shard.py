@@ -20,13 +20,19 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", 1)))
 
 
-def init(backend: str | None = None):
+def init(backend: str | None = None, force: bool = False):
+    """Join the job described by the torchrun environment.  With the nccl (= RCCL) backend
+    the rank's GPU is selected BEFORE the process group exists: every collective, the
+    object broadcast included, runs on the current device, and two ranks on one device
+    is an RCCL error.  `force` creates the group even for a single rank (self-tests)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"),
-                                rank=rank, world_size=world)
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
@@ -71,6 +77,8 @@ def gather_maps(local: torch.Tensor, total_pairs: int, rank: int, world: int):
     0, None elsewhere."""
     if world == 1:
         return local
+    if not dist.is_initialized():
+        raise RuntimeError("gather_maps: no process group (call shard.init first)")
     shape = tuple(local.shape[1:])
     counts = [len(pairs_for_rank(total_pairs, r, world)) for r in range(world)]
     if local.shape[0] != counts[rank]:

@@ -750,3 +750,25 @@ def test_step3_reports_a_zero_interval(hip):
     assert e.value.code == hip.capi.SM_ERR_ZERO_DIV
     plan.step3(torch.arange(48 * 64, dtype=torch.int32, device="cuda").view(1, 48, 64) + 1, 4, 10)  # flag cleared
     plan.close()
+
+
+def test_bench_rccl_calls_on_one_rank():
+    """The torch.distributed calls of the N > 1 bench path (object broadcast, barrier with
+    device ids, all-reduce MAX of the timing, collection on rank 0) on the real backend
+    -- nccl = RCCL -- with a one-rank group: all a one-GPU box can run of it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SM_BENCH_NCCL_SELFTEST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--config", "C2", "--steps", "6",
+                        "--warmup", "2", "--gather", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][0]
+    assert out["n_gpus"] == 1 and out["value"] > 0

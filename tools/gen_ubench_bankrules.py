@@ -78,7 +78,43 @@ def body(kind):
                       "mov": f"v_mov_b32 v{d}, v{r1}", "add": f"v_add_u32 v{d}, v{d}, v{r1}",
                       "lshlor": f"v_lshl_or_b32 v{d}, v{d}, 3, v{r1}", "andor": f"v_and_or_b32 v{d}, v{d}, v{r1}, v{r1}",
                       "cndmask": f"v_cndmask_b32 v{d}, v{d}, v{r1}, vcc", "readlane": f"v_readfirstlane_b32 s30, v{d}",
-                      "perm": f"v_perm_b32 v{d}, v{d}, v{r1}, v{r1}"}[m]
+                      "perm": f"v_perm_b32 v{d}, v{d}, v{r1}, v{r1}",
+                      "alignbyte": f"v_alignbyte_b32 v{d}, v{d}, v{r1}, 1",
+                      "bfi": f"v_bfi_b32 v{d}, v{d}, v{r1}, v{r1}",
+                      "lshl_add": f"v_lshl_add_u32 v{d}, v{d}, 3, v{r1}",
+                      "add_lshl": f"v_add_lshl_u32 v{d}, v{d}, v{r1}, 3",
+                      "pk_lshl16": f"v_pk_lshlrev_b16 v{d}, 3, v{d}",
+                      "lshl16": f"v_lshlrev_b16 v{d}, 3, v{d}",
+                      "mul_lo16": f"v_mul_lo_u16 v{d}, v{d}, v{r1}",
+                      "mad24": f"v_mad_u32_u24 v{d}, v{d}, v{r1}, v{r1}",
+                      "sdwa_mov": f"v_mov_b32_sdwa v{d}, v{r1} dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0",
+                      "lshl64": f"v_lshlrev_b64 v[{d & ~1}:{(d & ~1) + 1}], 3, v[{d & ~1}:{(d & ~1) + 1}]",
+                      "ashr": f"v_ashrrev_i32 v{d}, 3, v{d}",
+                      "bfrev": f"v_bfrev_b32 v{d}, v{d}",
+                      "cvt_ubyte": f"v_cvt_f32_ubyte1 v{d}, v{d}",
+                      "pk_add_f32": f"v_pk_add_f32 v[{d & ~1}:{(d & ~1) + 1}], v[{d & ~1}:{(d & ~1) + 1}], v[{r1 & ~1}:{(r1 & ~1) + 1}]",
+                      "fma": f"v_fma_f32 v{d}, v{d}, v{r1}, v{r1}",
+                      "max": f"v_max_f32 v{d}, v{d}, v{r1}",
+                      "max3": f"v_max3_f32 v{d}, v{d}, v{r1}, v{r1}",
+                      "cmp": f"v_cmp_le_f32 vcc, v{d}, v{r1}",
+                      "sad": f"v_sad_u32 v{d}, v{d}, v{r1}, v{r1}",
+                      "sub": f"v_sub_u32 v{d}, v{d}, v{r1}",
+                      "add3": f"v_add3_u32 v{d}, v{d}, v{r1}, v{r1}",
+                      "or3": f"v_or3_b32 v{d}, v{d}, v{r1}, v{r1}",
+                      "add_f32": f"v_add_f32 v{d}, v{d}, v{r1}",
+                      "cvt_i32": f"v_cvt_i32_f32 v{d}, v{d}",
+                      "lshl_by1_add": f"v_add_u32 v{d}, v{d}, v{d}",
+                      "xad": f"v_xad_u32 v{d}, v{d}, v{r1}, v{r1}",
+                      "mul_lo": f"v_mul_lo_u32 v{d}, v{d}, v{r1}",
+                      "bcnt": f"v_bcnt_u32_b32 v{d}, v{d}, v{r1}",
+                      "lshlrev_v": f"v_lshlrev_b32 v{d}, v{r1}, v{d}",
+                      "bpermute": f"ds_bpermute_b32 v200, v201, v{d}",
+                      "ds_read": "ds_read_b32 v200, v201",
+                      "ds_read_un": "ds_read_b32 v200, v201 offset:3",
+                      "ds_read2": "ds_read2_b32 v[202:203], v201 offset1:1",
+                      "ds_swizzle": f"ds_swizzle_b32 v200, v{d} offset:swizzle(SWAP,1)",
+                      "permlane": f"v_permlane32_swap_b32 v200, v{d}",
+                      "readlane": f"v_readlane_b32 s30, v{d}, 3"}[m]
                 out.append(op); continue
             s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
         elif kind.startswith("after "):
@@ -160,13 +196,10 @@ def body(kind):
         out.append(f"v_bitop3_b32 v{d}, v{d}, v{s1}, v{s2} bitop3:0x96")
     return "\\n".join(out)
 
-kinds = ["b3 distinct +skew", "mix 64 +skew", "after 64 branch +skew", "after 64 nop +skew", "after 64 nop7 +skew",
-         "after 64 sleep1 +skew", "after 64 waitcnt +skew", "after 16 branch +skew", "after 16 nop +skew",
-         "burstb 16 none +skew", "burstb 16 branch +skew", "burstb 16 nop +skew", "burstb 16 sleep1 +skew",
-         "burstb 64 branch +skew", "burstb 64 sleep1 +skew"]
+kinds = ["b3 distinct +skew"] + ["hr %s +skew" % n for n in ['bpermute', 'ds_read', 'ds_read_un', 'ds_read2', 'ds_swizzle', 'readlane']]
 src = ['// GENERATED by tools/gen_ubench_bankrules.py -- do not edit', '#include <hip/hip_runtime.h>',
        '#include <cstdio>', '#include <vector>', '#include <map>', '#include <algorithm>', '']
-clob = ", ".join(f'"v{i}"' for i in range(8, 202)) + ', "vcc", "s30"'
+clob = ", ".join(f'"v{i}"' for i in range(8, 204)) + ', "vcc", "s30"'
 for k, kind in enumerate(kinds):
     src.append(f'__global__ __launch_bounds__(64) void k{k}(unsigned *out, unsigned long long *info, int iters)\n{{')
     src.append('    unsigned seed = threadIdx.x * 2654435761u + blockIdx.x;')
