@@ -256,6 +256,9 @@ __device__ __forceinline__ void addsub_planes(u32 (&s)[SB], const u32 (&hn)[HB],
 #ifndef SM_BS_SLICE
 #define SM_BS_SLICE 16    // swap every 65536 cycles (~31 us): 13 / 15 / 17 measured slower
 #endif
+#ifndef SM_BS_PATTERN
+#define SM_BS_PATTERN 0xF0F0F0F0u   // 4 units (65536 cycles) per slice; 2 / 3 / 6 units and the inverse measured
+#endif
 #ifndef SM_BS_NOP
 #define SM_BS_NOP 3
 #endif
@@ -460,8 +463,12 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
 #if SM_BS_SLICE
     // Time-sliced priority: the wave whose hardware slot parity equals bit SM_BS_SLICE of
     // the shader clock runs at raised priority, the other at 0, and the roles swap every
-    // 2^SM_BS_SLICE cycles -- both read the same clock, so exactly one of a pair is
-    // favoured at any time.  The SIMD serves its favoured wave at the rate of a wave alone
+    // 2^SM_BS_SLICE cycles (with SM_BS_PATTERN: after a schedule counted from the wave's own
+    // start) -- both read the same clock, so exactly one of a pair is favoured at any time.
+    // (A feedback variant -- every wave publishes its finished rows per SIMD and slot in
+    // global memory, the one that is behind takes the priority -- was built and measured
+    // slower, 96.6 vs 91.3 us: a store, a load and a v_readfirstlane per row, and the waves
+    // still finished 15 us apart.)  The SIMD serves its favoured wave at the rate of a wave alone
     // and gives the other what is left (measured: 4.9 vs 9.0 cycles per instruction here);
     // without the swap the favoured wave finishes a third earlier and the SIMD then runs
     // half empty until the other is done.
@@ -469,11 +476,24 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     // the clock is read one row ahead of its use (s_memtime is a scalar memory read: its
     // value takes ~100 cycles to arrive, and a wave that uses it at once waits that long)
     unsigned long long clk = __builtin_amdgcn_s_memtime();
+#if SM_BS_PATTERN
+    // slices counted from the wave's own start (the waves of a launch start within 0.5 us of
+    // each other): bit k of SM_BS_PATTERN says which slot parity is favoured during the
+    // k-th 16384-cycle unit, so the schedule is the same in every launch
+    const unsigned long long clk0 = clk;
+#define SM_SLICE_PRIO()                                                               \
+    do {                                                                              \
+        const unsigned unit_ = (unsigned)((clk - clk0) >> 14) & 31u;                  \
+        if ((((unsigned)SM_BS_PATTERN >> unit_) ^ slot_parity) & 1) __builtin_amdgcn_s_setprio(3); \
+        else __builtin_amdgcn_s_setprio(0);                                           \
+    } while (0)
+#else
 #define SM_SLICE_PRIO()                                                               \
     do {                                                                              \
         if ((((unsigned)(clk >> SM_BS_SLICE)) ^ slot_parity) & 1) __builtin_amdgcn_s_setprio(3); \
         else __builtin_amdgcn_s_setprio(0);                                           \
     } while (0)
+#endif
 #define SM_SLICE_READ() do { clk = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SM_SLICE_PRIO() do { } while (0)
@@ -686,8 +706,8 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     // steady-state loop below has ONE code path updating S (with both in one loop the
     // register allocator met two definitions of every sum plane at the join and paid
     // 16 x SB register copies per row for it).
-#pragma unroll 1
     SM_SLICE_PRIO();                // the warm-up rows are shorter than one time slice
+#pragma unroll 1
     for (int e = 0; e < N; e++) slide_in(e);
     SM_SLICE_READ();
     SM_STAMP(2);
