@@ -176,10 +176,16 @@ template <int B> __device__ __forceinline__ float cvt_ubyte(u32 q)
 // (src/stereo.c:16-70).  `exact` (ghost pixels on or outside the image border,
 // whose sums contain the 128.0 halo and are outside the tables; or no usable
 // tables at all) takes the double arithmetic of the reference.
+// `known_edge`: a ghost-mode pixel ON the image border of an image at least 2 x 2.  One of
+// its axis-aligned tests has three halo pixels (128.0 each) on one side and only in-image
+// pixels (< 1.0 each) on the other -- or, at a corner, two halo pixels more on one side than
+// on the other -- so the side means differ by more than 40 while the limit is clamped to
+// [0, 1] (src/stereo-ghost.c:18-30): it is an edge for every threshold, and no arithmetic
+// is spent on it (the double path it used to take made ghost-mode edges 4x slower).
 template <bool TABLES>
 __device__ __forceinline__ u32 edge_decide(const float (&sa)[4], const float (&sb)[4],
                                            const u32 *__restrict__ tab, double threshold,
-                                           float neg_t, bool exact)
+                                           float neg_t, bool exact, bool known_edge = false)
 {
     u32 e;
     if (TABLES) {
@@ -190,7 +196,7 @@ __device__ __forceinline__ u32 edge_decide(const float (&sa)[4], const float (&s
         e = __float_as_uint(SM_EDGE_MARGIN - dmax) >> 31;                 // dmax > margin
         // rare: the deciding sum pair is next to the boundary -> ask the table
         // (never with halo sums: they are not table indices)
-        if (!exact && __builtin_fabsf(dmax) <= SM_EDGE_MARGIN) {
+        if (!exact && !known_edge && __builtin_fabsf(dmax) <= SM_EDGE_MARGIN) {
 #pragma unroll
             for (int o = 0; o < 4; o++)
                 if (dl[o] >= -SM_EDGE_MARGIN)
@@ -203,7 +209,7 @@ __device__ __forceinline__ u32 edge_decide(const float (&sa)[4], const float (&s
         for (int o = 0; o < 4; o++)
             e |= contrast_test((int)sa[o], (int)sb[o], threshold) ? 1u : 0u;
     }
-    return e;
+    return known_edge ? 1u : e;
 }
 
 // Edge detection straight into the packed ext image.  No LDS, no barrier: a
@@ -287,8 +293,10 @@ __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
                              v[2][0] + v[2][1] + v[2][2],      // bottom
                              v[1][2] + v[2][1] + v[2][2],      // down-right
                              v[0][1] + v[0][2] + v[1][2]};     // up-right
-        const bool exact = GHOST && !(inner_x && y > 0 && y < g.h - 1);
-        const u32 e = edge_decide<TABLES>(sa, sb, tab, threshold, neg_t, exact);
+        const bool on_border = GHOST && !(inner_x && y > 0 && y < g.h - 1);
+        const bool big = g.w >= 2 && g.h >= 2;         // uniform
+        const bool exact = on_border && !(TABLES && big);
+        const u32 e = edge_decide<TABLES>(sa, sb, tab, threshold, neg_t, exact, on_border && TABLES && big);
         const u32 val = e & in_x & ((!GHOST || in_y) ? 1u : 0u);
         if (store_x && in_y) edges[img + (size_t)y * g.w + x] = (u8)val;
         const unsigned long long bal = __ballot(val != 0);
@@ -417,7 +425,11 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
         const int ye = ye0 + rr;
         const int y = ye - g.half;
         const bool in_y = y >= 0 && y < g.h;         // uniform
-        const bool exact = GHOST && !(inner_x && y > 0 && y < g.h - 1);
+        // ghost: pixels on the image border are edges by construction (edge_decide); only
+        // images narrower or lower than 2 keep the double path for them
+        const bool big = g.w >= 2 && g.h >= 2;                       // uniform
+        const bool row_border = GHOST && (y <= 0 || y >= g.h - 1);   // uniform
+        const bool exact = GHOST && !(TABLES && big) && !(inner_x && y > 0 && y < g.h - 1);
         float col[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) col[k] = v[0][k] + v[1][k] + v[2][k];
@@ -433,7 +445,8 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
                                  s3[2][q],                     // bottom
                                  p[2][q + 1] + v[1][q + 2],    // down-right
                                  p[0][q + 1] + v[1][q + 2]};   // up-right
-            nib |= edge_decide<TABLES>(sa, sb, tab, threshold, neg_t, exact) << q;
+            const bool known = GHOST && TABLES && big && (row_border || x + q <= 0 || x + q >= g.w - 1);
+            nib |= edge_decide<TABLES>(sa, sb, tab, threshold, neg_t, exact, known) << q;
         }
         if (!in_ext || (GHOST && !(quad_in && in_y))) nib = 0;
         const bool row_ok = ye < g.ext_rows;         // uniform; the last strip may be short
