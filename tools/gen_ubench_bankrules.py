@@ -128,6 +128,13 @@ def body(kind):
                             "cbranch": "s_cbranch_vccz 0", "setpc": "s_nop 0", "barrier": "s_barrier",
                             "waitcnt": "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)"}[what]); continue
             s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
+        elif kind.startswith("burst1 "):
+            # ONE burst of b half-rate instructions per body, starting at position p0
+            _, b, p0 = kind.split()
+            b, p0 = int(b), int(p0)
+            if p0 <= i < p0 + b:
+                out.append(f"v_alignbit_b32 v{d}, v{d}, v{reg_in_bank(b0 + 1, k)}, 7"); continue
+            s1, s2 = reg_in_bank(b0 + 1, k), reg_in_bank(b0 + 2, k)
         elif kind.startswith("burstb "):
             # b alignbits, then a re-phasing instruction, then full-rate code; period 512
             _, b, what = kind.split()
@@ -196,7 +203,7 @@ def body(kind):
         out.append(f"v_bitop3_b32 v{d}, v{d}, v{s1}, v{s2} bitop3:0x96")
     return "\\n".join(out)
 
-kinds = ["b3 distinct +skew"] + ["hr %s +skew" % n for n in ['bpermute', 'ds_read', 'ds_read_un', 'ds_read2', 'ds_swizzle', 'readlane']]
+kinds = ["b3 distinct +skew", "burst1 16 0 +skew", "burst1 64 0 +skew", "burst1 16 8 +skew", "burst1 16 64 +skew", "burst1 16 512 +skew", "burst1 64 512 +skew", "burst1 1 1 +skew", "burst1 1 4 +skew", "burst1 1 16 +skew"]
 src = ['// GENERATED by tools/gen_ubench_bankrules.py -- do not edit', '#include <hip/hip_runtime.h>',
        '#include <cstdio>', '#include <vector>', '#include <map>', '#include <algorithm>', '']
 clob = ", ".join(f'"v{i}"' for i in range(8, 204)) + ', "vcc", "s30"'
