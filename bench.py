@@ -101,20 +101,36 @@ def launch_ranks(n: int, argv: list[str]) -> int:
         # rank 0's stdout is the JSON line; every other rank's goes to our stderr
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
     try:
-        out0, _ = procs[0].communicate()
-        sys.stdout.write(out0.decode())
-        sys.stdout.flush()
+        # a rank that dies leaves the others waiting in a rendezvous or a barrier: as soon as
+        # one exits with an error the rest are stopped (exact PIDs we started, never a pattern)
+        while any(p.poll() is None for p in procs):
+            failed = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+            if failed:
+                rc = abs(failed[0])
+                break
+            time.sleep(0.05)
         for p in procs:
-            rc = max(rc, abs(p.wait()))
+            if p.poll() is not None:
+                rc = max(rc, abs(p.returncode))
     except BaseException:
         rc = rc or 1
         raise
     finally:
-        for p in procs:                 # exact PIDs we started, never a pattern
+        for p in procs:
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            p.wait()
+        reader.join(timeout=5)
+    if out0 and out0[0]:
+        sys.stdout.write(out0[0].decode())
+        sys.stdout.flush()
     return rc
 
 
