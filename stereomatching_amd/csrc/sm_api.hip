@@ -379,7 +379,12 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
     bool vy[R + 2];
     {
         int y_img = ye0 - g.half - 1;
-        int ys = GHOST ? y_img : pos_mod(y_img, g.h);
+        // wrapped source row of the strip's first row: y_img >= -half - 1 >= -h always; one
+        // conditional add or subtract covers up to 2h, the division (a few dozen scalar
+        // instructions per wave, on the CU's one scalar unit: 6 % of this kernel's time) is
+        // left for the round-up rows of very small images
+        int ys = y_img;
+        if (!GHOST) ys = y_img < 0 ? y_img + g.h : (y_img < g.h ? y_img : (y_img < 2 * g.h ? y_img - g.h : pos_mod(y_img, g.h)));
 #pragma unroll
         for (int k = 0; k < R + 2; k++) {
             vy[k] = !GHOST || (y_img >= 0 && y_img < g.h);
