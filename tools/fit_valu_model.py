@@ -23,9 +23,11 @@ for meta_file in sorted(src.glob("*/meta.json")):
     meta = json.loads(meta_file.read_text())
     vals, waves = [], []
     for f in glob.glob(str(meta_file.parent / "prof" / "*" / "*_counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
-            if "k_match" not in r["Kernel_Name"]:
-                continue
+        rows = [r for r in csv.DictReader(open(f)) if "k_match" in r["Kernel_Name"]]
+        full = max((int(r["Grid_Size"]) for r in rows), default=0)
+        for r in rows:
+            if int(r["Grid_Size"]) != full:
+                continue                    # the plan's one-workgroup set-up launch
             if r["Counter_Name"] == "SQ_INSTS_VALU":
                 vals.append(float(r["Counter_Value"]))
             if r["Counter_Name"] == "SQ_WAVES":
