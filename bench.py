@@ -70,9 +70,10 @@ def parse(argv=None):
                          "(sm_plan_set_pipelined; measured: no net gain, both kernels are VALU-heavy)")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region, collect the maps on rank 0 over RCCL and time it")
-    ap.add_argument("--e2e", action="store_true",
-                    help="also measure the PCIe-inclusive rate through the C ABI alone (pinned "
-                         "buffers, async copies) and report it as an extra `e2e` object")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the extra `e2e` object (N = 1 only): the PCIe-inclusive rate through the "
+                         "C ABI alone (pinned buffers, async copies), measured after the timed region; "
+                         "it is never part of `value`")
     return ap.parse_args(argv)
 
 
@@ -404,7 +405,7 @@ def main():
         out["rehearsal"] = "SM_BENCH_REHEARSAL: all ranks on device 0 over gloo"
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
-    if args.e2e and world == 1:
+    if world == 1 and not args.no_e2e and not rehearsal:
         from tools import e2e_bench
         out["e2e"] = e2e_bench.measure(args.config, local_rank)
     if world == 1 and not args.no_cpu_baseline:

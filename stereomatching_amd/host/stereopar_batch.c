@@ -9,9 +9,9 @@
  * parameters and validation, same stages up to the web map -- and adds what
  * the reference does not have: pair j goes to device j mod n_devices (no
  * exchange between devices: pairs are independent), each device has its own
- * host thread, plan, streams and pinned staging buffers, and uploads, kernels
- * and downloads of neighbouring batches overlap (two slots in flight per
- * device).  Results come back as NARROW web maps (uint8 when the shifts fit,
+ * host thread, plans and streams; the images are decoded into one pinned arena
+ * and uploaded straight from it; uploads, kernels and downloads of neighbouring
+ * batches overlap (two slots in flight per device).  Results come back as NARROW web maps (uint8 when the shifts fit,
  * else uint16: sm_run_typed), a quarter / half of the int32 PCIe traffic.
  *
  *   stereopar-batch [options] LIST [threshold] [square_width]
@@ -53,7 +53,7 @@
 
 typedef struct {
     char *left, *right;
-    uint8_t *px[2];        /* decoded samples */
+    uint8_t *px[2];        /* decoded samples, in the pinned arena (see main) */
 } Pair;
 
 typedef struct {
@@ -130,6 +130,30 @@ static void write_pgm(const char *dir, int index, const void *web, int bytes, in
     fclose(f);
 }
 
+/* sum of n bytes, eight at a time: the even and the odd bytes of a 64-bit word are added into
+ * four 16-bit lanes (each step adds at most 510 to a lane, so 128 steps fit), which are
+ * folded into the total before they can overflow.  The map sums are on the host thread's
+ * critical path between two batches. */
+static unsigned long long sum_bytes(const uint8_t *p, size_t n)
+{
+    const unsigned long long M = 0x00ff00ff00ff00ffULL;
+    unsigned long long total = 0;
+    size_t i = 0;
+    while (i + 8 <= n) {
+        unsigned long long lanes = 0;
+        size_t steps = (n - i) / 8;
+        if (steps > 128) steps = 128;
+        for (size_t k = 0; k < steps; k++, i += 8) {
+            unsigned long long w;
+            memcpy(&w, p + i, 8);
+            lanes += (w & M) + ((w >> 8) & M);
+        }
+        total += (lanes & 0xffff) + ((lanes >> 16) & 0xffff) + ((lanes >> 32) & 0xffff) + (lanes >> 48);
+    }
+    for (; i < n; i++) total += p[i];
+    return total;
+}
+
 /* one device: its share of the pairs, two batches in flight */
 static void *worker_main(void *arg)
 {
@@ -140,7 +164,7 @@ static void *worker_main(void *arg)
     const int web_bytes = web_type == SM_WEB_U8 ? 1 : 2;
     sm_plan *plan[SLOTS] = {NULL};
     void *stream[SLOTS] = {NULL};
-    uint8_t *h_in[SLOTS] = {NULL}, *d_in[SLOTS] = {NULL};
+    uint8_t *d_in[SLOTS] = {NULL};
     void *h_web[SLOTS] = {NULL}, *d_web[SLOTS] = {NULL};
     int in_flight[SLOTS] = {0}, first_index[SLOTS] = {0};
 
@@ -155,10 +179,22 @@ static void *worker_main(void *arg)
                            w->batch, &plan[s]) ||
             sm_plan_prepare_threshold(plan[s], w->threshold, NULL) ||
             sm_stream_create(dev, &stream[s]) ||
-            sm_host_alloc(2 * n * w->batch, (void **)&h_in[s]) ||
             sm_host_alloc(n * web_bytes * w->batch, &h_web[s]) ||
             sm_malloc(dev, 2 * n * w->batch, (void **)&d_in[s]) ||
             sm_malloc(dev, n * web_bytes * w->batch, &d_web[s])) {
+            snprintf(w->error, sizeof w->error, "%s", sm_last_error());
+            w->failed = 1;
+        }
+    }
+    /* one pair through every slot before the clock starts: the first transfer and the first
+     * launch on a stream set up DMA queues and load code objects (tens of milliseconds) */
+    for (int s = 0; s < SLOTS && !w->failed && mine > 0; s++) {
+        const int j = w->rank;
+        if (sm_memcpy_h2d_async(dev, d_in[s], w->pairs[j].px[0], n, stream[s]) ||
+            sm_memcpy_h2d_async(dev, d_in[s] + n, w->pairs[j].px[1], n, stream[s]) ||
+            sm_run_typed(plan[s], d_in[s], d_in[s] + n, w->threshold, 1, d_web[s], web_type, NULL, stream[s]) ||
+            sm_memcpy_d2h_async(dev, h_web[s], d_web[s], n * web_bytes, stream[s]) ||
+            sm_stream_sync(dev, stream[s])) {
             snprintf(w->error, sizeof w->error, "%s", sm_last_error());
             w->failed = 1;
         }
@@ -176,10 +212,12 @@ static void *worker_main(void *arg)
             for (int k = 0; k < in_flight[s]; k++) {
                 const uint8_t *m8 = (const uint8_t *)h_web[s] + (size_t)k * n * web_bytes;
                 unsigned long long sum = 0;
-                if (web_bytes == 1)
-                    for (size_t i = 0; i < n; i++) sum += m8[i];
-                else
-                    for (size_t i = 0; i < n; i++) sum += ((const uint16_t *)m8)[i];
+                if (web_bytes == 1) {
+                    sum = sum_bytes(m8, n);
+                } else {            /* little-endian uint16: low bytes + 256 * high bytes */
+                    const uint16_t *m16 = (const uint16_t *)m8;
+                    for (size_t i = 0; i < n; i++) sum += m16[i];
+                }
                 w->checksum += sum;
                 const long seq = first_index[s] + k;                 /* in this device's sequence */
                 const int j = w->rank + (int)(seq % mine) * w->n_devices;   /* global pair index */
@@ -190,17 +228,15 @@ static void *worker_main(void *arg)
             in_flight[s] = 0;
         }
         if (next < total) {
-            /* stage the next batch: lefts then rights, as sm_run expects a batch */
+            /* upload the next batch straight from the pinned arena the images were decoded
+             * into: lefts then rights, as sm_run expects a batch (no staging copy on the host) */
             int b = 0;
-            for (; b < w->batch && next + b < total; b++) {
-                const int j = w->rank + (int)((next + b) % mine) * w->n_devices;
-                memcpy(h_in[s] + (size_t)b * n, w->pairs[j].px[0], n);
-            }
+            while (b < w->batch && next + b < total) b++;
             for (int k = 0; k < b; k++) {
                 const int j = w->rank + (int)((next + k) % mine) * w->n_devices;
-                memcpy(h_in[s] + (size_t)(b + k) * n, w->pairs[j].px[1], n);
+                W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)k * n, w->pairs[j].px[0], n, stream[s]));
+                W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)(b + k) * n, w->pairs[j].px[1], n, stream[s]));
             }
-            W_TRY(sm_memcpy_h2d_async(dev, d_in[s], h_in[s], 2 * n * b, stream[s]));
             W_TRY(sm_run_typed(plan[s], d_in[s], d_in[s] + (size_t)b * n, w->threshold, b, d_web[s],
                                web_type, NULL, stream[s]));
             W_TRY(sm_memcpy_d2h_async(dev, h_web[s], d_web[s], n * web_bytes * b, stream[s]));
@@ -214,7 +250,6 @@ out:
     for (int k = 0; k < SLOTS; k++) {
         if (stream[k]) { sm_stream_sync(dev, stream[k]); sm_stream_destroy(dev, stream[k]); }
         if (plan[k]) sm_plan_destroy(plan[k]);
-        if (h_in[k]) sm_host_free(h_in[k]);
         if (h_web[k]) sm_host_free(h_web[k]);
         if (d_in[k]) sm_free(dev, d_in[k]);
         if (d_web[k]) sm_free(dev, d_web[k]);
@@ -314,16 +349,26 @@ int main(int argc, char *argv[])
     if (n_pairs == 0)
         return fail("error: the pair list is empty");
 
-    /* decode (before the clock starts, as the reference reads its images before t1) */
+    /* decode (before the clock starts, as the reference reads its images before t1) into ONE
+     * pinned arena, so that the uploads need no staging copy */
     int width = 0, height = 0;
+    uint8_t *arena = NULL;
     for (int j = 0; j < n_pairs; j++) {
         for (int side = 0; side < 2; side++) {
             int wd, ht;
-            if (read_image_u8(side ? pairs[j].right : pairs[j].left, &pairs[j].px[side], &wd, &ht))
+            uint8_t *px = NULL;
+            if (read_image_u8(side ? pairs[j].right : pairs[j].left, &px, &wd, &ht))
                 return 1;
-            if (j == 0 && side == 0) { width = wd; height = ht; }
+            if (j == 0 && side == 0) {
+                width = wd; height = ht;
+                if (sm_host_alloc((size_t)2 * n_pairs * wd * ht, (void **)&arena) != SM_OK)
+                    return fail(sm_last_error());
+            }
             if (wd != width || ht != height)
                 return fail("error: the two images must have equal width and height");
+            pairs[j].px[side] = arena + ((size_t)2 * j + side) * wd * ht;
+            memcpy(pairs[j].px[side], px, (size_t)wd * ht);
+            free(px);
         }
     }
     if (square_width > width || square_width > height)
@@ -383,8 +428,9 @@ int main(int argc, char *argv[])
            "pairs_per_s = %f, checksum = %llu\n",
            done, n_devices, width, height, num_shifts, elapsed, done / elapsed, checksum);
     for (int j = 0; j < n_pairs; j++) {
-        free(pairs[j].left); free(pairs[j].right); free(pairs[j].px[0]); free(pairs[j].px[1]);
+        free(pairs[j].left); free(pairs[j].right);
     }
     free(pairs);
+    sm_host_free(arena);
     return 0;
 }

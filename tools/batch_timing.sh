@@ -13,6 +13,8 @@ for j in range(8):
     lines.append(f'gpurun_out/batch/l{j}.pgm gpurun_out/batch/r{j}.pgm')
 open('gpurun_out/batch/list.txt', 'w').write('\n'.join(lines) + '\n')
 PY
-for b in 1 4 8; do
-  echo "pairs per launch $b: $(./timing/stereopar-batch -n 64 -b $b -r 8 gpurun_out/batch/list.txt 0.15 7)"
+for r in ${REPEATS:-8 64}; do
+  for b in 1 4 8; do
+    echo "repeat $r, pairs per launch $b: $(./timing/stereopar-batch -n 64 -b $b -r $r gpurun_out/batch/list.txt 0.15 7)"
+  done
 done

@@ -3,7 +3,7 @@
 pinned host memory, results end in pinned host memory.  Three streams' worth of
 work are kept in flight (upload of pair k+1, kernels of pair k, download of pair
 k-1) with per-slot buffers and plans.  This is NOT bench.py's `value` (which is
-measured with resident inputs); bench.py --e2e reports it as an extra object and
+measured with resident inputs); bench.py (N = 1) reports it as the extra object `e2e` and
 DESIGN.md quotes it next to the resident number.
 
     python tools/e2e_bench.py [C3] [pairs=24] [slots=3]
