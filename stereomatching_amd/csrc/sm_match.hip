@@ -632,15 +632,27 @@ int sm_match_configure(sm_plan *plan)
     // built for this window (16 where it exists: measured faster than 8, fewer shared
     // views and merge levels), SM_DS overrides for tuning
     int ds = 16;
+    MatchGeom gsel;
+    int rws = 0;
     if (bs) {
         ds = sm_bs_default_ds(g.n);
         int l2;
+        const bool has8 = sm_bs_kernel_ptr(g.n, 8, true, ghost, false) && nl_for(8, l2) <= 32;
         if ((ds_env == 8 || ds_env == 16) && sm_bs_kernel_ptr(g.n, ds_env, true, ghost, false) &&
-            nl_for(ds_env, l2) <= 32)
+            nl_for(ds_env, l2) <= 32) {
             ds = ds_env;
+        } else if (ds == 16 && has8) {
+            // A grid that leaves most SIMDs with ONE wave (a single 1080p pair: 864 workgroups)
+            // runs at the rate of a lone wave; with 8 shifts per lane the same job is twice the
+            // workgroups of roughly half the work each, i.e. two waves per SIMD.  The cost model
+            // decides (measured: C2 29.6 -> 23.4 us, C1 18.4 -> 12.0 us; the full-chip
+            // configurations stay at 16).
+            MatchGeom g16, g8;
+            int r16 = 0, r8 = 0;
+            const double c16 = configure(16, g16, r16), c8 = configure(8, g8, r8);
+            if (c8 < 0.95 * c16) ds = 8;
+        }
     }
-    MatchGeom gsel;
-    int rws = 0;
     configure(ds, gsel, rws);
     g = gsel;
 

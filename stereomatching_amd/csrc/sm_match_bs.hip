@@ -1044,7 +1044,11 @@ const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost, bool cap2)
     }
     if (ds == 8) {
         switch (n) {
+        case 3: return bs_ptr<3, 8, true>(fulld, ghost, cap2);
+        case 5: return bs_ptr<5, 8, true>(fulld, ghost, cap2);
+        case 7: return bs_ptr<7, 8, true>(fulld, ghost, cap2);
         case 9: return bs_ptr<9, 8, true>(fulld, ghost, cap2);
+        case 11: return bs_ptr<11, 8, true>(fulld, ghost, cap2);
         case 13: return bs_ptr<13, 8, true>(fulld, ghost, cap2);
         case 15: return bs_ptr<15, 8, true>(fulld, ghost, cap2);
         case 17: return bs_ptr<17, 8, false>(fulld, ghost, cap2);
