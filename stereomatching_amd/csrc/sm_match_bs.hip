@@ -583,6 +583,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
     auto rview = [&](const RowViews &v, int j) -> u32 {
         return (j & 31) ? alignbit(v.rw[(j >> 5) + 1], v.rw[j >> 5], j & 31) : v.rw[j >> 5];
     };
+#if !SM_BS_LOCKSTEP
     // mismatch count of shift dd in one row (win = the N right views of this shift)
     auto count_row = [&](const RowViews &v, const u32 (&win)[N], u32 (&h)[HB]) {
         u32 x[N];
@@ -591,6 +592,7 @@ __global__ __launch_bounds__(64, SM_BS_WAVES) void k_match_bs(const u32 *__restr
             x[i] = GHOST ? bop<BOP_XOR_AND>(v.lv[i], win[i], cvv[i]) : (v.lv[i] ^ win[i]);
         count_bits<N, HB>(x, h);
     };
+#endif
 
 #if SM_BS_LOCKSTEP
     constexpr int GW = DS >= 4 ? 4 : DS;      // shifts side by side in a warm-up row
