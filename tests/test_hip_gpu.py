@@ -433,6 +433,19 @@ def test_pipelined_runs_and_kernel_timing(hip):
     with pytest.raises(hip.capi.StereoHipError, match="sm_plan_time_stride"):
         plan.time_kernels(4, every=0)
     plan.time_kernels(0)
+    # ordered pipelining (mode 2): the inputs of each run are produced on the launch stream
+    # immediately before it (an asynchronous copy into a reused buffer); the edge kernel on the
+    # plan's internal stream must wait for them
+    plan.set_pipelined(2)
+    buf_l, buf_r = torch.empty_like(inputs[0][0]), torch.empty_like(inputs[0][1])
+    for i in range(2 * len(inputs)):
+        a, b = inputs[i % len(inputs)]
+        buf_l.copy_(a, non_blocking=True)
+        buf_r.copy_(b, non_blocking=True)
+        got = plan.run(buf_l, buf_r, 0.15)[0].clone()
+        torch.cuda.synchronize()
+        assert np.array_equal(host(got)[0], want[i % len(inputs)]), i
+    plan.set_pipelined(False)
     plan.close()
 
 
