@@ -75,3 +75,25 @@ def test_synth_and_pgm_roundtrip(tmp_path):
     assert np.array_equal(a, a2) and np.array_equal(b, b2) and a.dtype == np.uint8
     write_pgm(tmp_path / "x.pgm", a)
     assert np.array_equal(read_pgm(tmp_path / "x.pgm"), a)
+
+
+def test_valu_model_reproduces_the_profiled_count():
+    """The analytic VALU model behind bench.py's roofline: for the headline geometry (C3: 15 x
+    135 one-wave tiles of 16 rows) it must land on the SQ_INSTS_VALU the r02 profile holds,
+    and every fitted variant must have kept its residual small."""
+    import json
+    from pathlib import Path
+
+    from stereomatching_amd import valu_model
+    root = Path(__file__).resolve().parent.parent
+    geom = dict(kernel=4, window=9, shifts_per_lane=16, shift_lanes=8, threads=64, tile_w=256, tile_h=16,
+                tiles_x=15, tiles_y=135)
+    m = valu_model.match_launch(geom, 3840, 2160, 128, 0, 1, want_best=False)
+    assert m is not None and m["variant"] == "k4:n9:ds16:nl8:toroidal:fulld1:best0"
+    prof = json.loads((root / "profiles" / "r02" / "pmc_summary.json").read_text())
+    counted = [v["SQ_INSTS_VALU"] for k, v in prof.items() if k.startswith("k_match_bs<9, 16")][0]
+    assert abs(m["wave_instructions"] - counted) / counted < 0.005
+    table = json.loads(valu_model.COUNTS.read_text())
+    assert all(v["max_rel_residual"] < 0.005 for v in table["variants"].values())
+    # a variant nobody fitted gives no number rather than a wrong one
+    assert valu_model.match_launch(dict(geom, window=13), 3840, 2160, 128, 0, 1) is None
