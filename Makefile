@@ -25,7 +25,10 @@ HIPCC  ?= /opt/rocm/bin/hipcc
 CFLAGS := -std=gnu11 -Wall -Wextra -pedantic -Wno-unused-parameter -Iinclude -Ioracle $(MODE_FLAGS_$(build))
 
 HOSTDIR := stereomatching_amd/host
-KERNELS := $(addprefix stereomatching_amd/csrc/,sm_api.hip sm_match.hip sm_match_bs.hip sm_cost.hip)
+CSRC    := stereomatching_amd/csrc
+KERNELS := sm_match_bs_ds8 sm_match_bs sm_match_bs_duo8 sm_match_bs_duo sm_api sm_match sm_cost
+DEVOBJ  := $(addprefix stereomatching_amd/obj/make/,$(addsuffix .o,$(KERNELS)))
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Iinclude -I$(CSRC)
 DEVLIB  := stereomatching_amd/libstereo_hip.so
 LINKDEV := -Lstereomatching_amd -lstereo_hip -Wl,-rpath,'$$ORIGIN/../stereomatching_amd'
 
@@ -38,9 +41,12 @@ all: $(CPU_PROGRAMS) $(GPU_PROGRAMS) $(BATCH_PROGRAM)
 $(O):
 	mkdir -p $@
 
-$(DEVLIB): $(KERNELS) stereomatching_amd/csrc/sm_internal.h include/stereo_hip.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize \
-	    -Iinclude -Istereomatching_amd/csrc $(KERNELS) -o $@
+# (the bit-sliced kernel's builds are four translation units: `make -j4` compiles them side by side)
+stereomatching_amd/obj/make/%.o: $(CSRC)/%.hip $(CSRC)/sm_internal.h $(CSRC)/sm_match_bs_kernel.h include/stereo_hip.h
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(DEVLIB): $(DEVOBJ)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
 
 $(O)/image.o: $(HOSTDIR)/image.c include/image.h | $(O)
 	$(CC) $(CFLAGS) -c $< -o $@

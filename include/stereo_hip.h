@@ -95,12 +95,14 @@ typedef struct sm_geometry {
     int shifts_per_lane;   /* shifts one lane carries */
     int shift_lanes;       /* lanes that split one pixel group's shift range */
     int threads;           /* per workgroup */
-    int tile_w, tile_h;    /* output pixels per workgroup */
+    int tile_w, tile_h;    /* output pixels per workgroup (tile_h / waves_per_workgroup rows per wave) */
     int tiles_x, tiles_y;  /* grid (x pairs in z) */
     int ext_words, ext_rows, pad_l;   /* packed edge image: u32 words per row, rows, left pad px */
     int lds_bytes;         /* dynamic LDS request per workgroup */
     int two_wave_variant;  /* bit-sliced kernel capped at two waves per SIMD */
     int edge_rows_per_wave;/* packed-image rows one wave of the edge kernel produces */
+    int waves_per_workgroup; /* bit-sliced kernel: 1, or 2 = the upper and the lower half of a tile,
+                              * sharing the window rows around the middle */
 } sm_geometry;
 int sm_plan_geometry(const sm_plan *plan, sm_geometry *out);
 /* bytes of private device workspace */

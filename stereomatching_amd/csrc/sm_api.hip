@@ -883,7 +883,7 @@ extern "C" int sm_plan_geometry(const sm_plan *plan, sm_geometry *out)
     out->shift_lanes = g.nl;
     out->threads = g.threads;
     out->tile_w = g.tw;
-    out->tile_h = g.tile_h;
+    out->tile_h = g.duo ? 2 * g.tile_h : g.tile_h;
     out->tiles_x = g.tiles_x;
     out->tiles_y = g.tiles_y;
     out->ext_words = g.ext_words;
@@ -892,6 +892,7 @@ extern "C" int sm_plan_geometry(const sm_plan *plan, sm_geometry *out)
     out->lds_bytes = g.lds_bytes;
     out->two_wave_variant = g.cap2;
     out->edge_rows_per_wave = (g.w % 4 == 0) ? SM_EDGE4_ROWS : SM_EDGE_ROWS;
+    out->waves_per_workgroup = plan->kernel == SM_KERNEL_BS ? (g.duo ? 2 : 1) : (g.threads + 63) / 64;
     return SM_OK;
 }
 

@@ -504,7 +504,7 @@ int sm_match_configure(sm_plan *plan)
         g.ext_rows = H + 2 * g.half;
         g.ext_image_words = (long long)g.ext_words * g.ext_rows;
         g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = g.ds = 0;
-        g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = g.cap2 = 0;
+        g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = g.cap2 = g.duo = 0;
         snprintf(plan->describe, sizeof plan->describe,
                  "generic kernel (n=%d, D=%d): 1 lane/pixel, direct window sums", g.n, D);
         return SM_OK;
@@ -527,15 +527,16 @@ int sm_match_configure(sm_plan *plan)
     // costs as much as a full one.  Model: a workgroup puts threads/256 waves on each
     // SIMD; a SIMD issues one wave-instruction per 2 cycles, a single wave at most one
     // per 4; rounds run back to back; the work of a lane-row is proportional to ds.
-    auto configure = [&](int ds, MatchGeom &o, int &rows_words_o) -> double {
+    auto configure = [&](int ds, MatchGeom &o, int &rows_words_o, bool duo = false) -> double {
         o = g;
         o.ds = ds;
+        o.duo = duo ? 1 : 0;
         o.nl = nl_for(ds, o.log2nl);
         int rows_words;
         if (bs) {
             // one wave per workgroup: 64/nl words of 32 pixels, nl shift-lanes each
             o.runs = 64 / o.nl;
-            o.threads = 64;
+            o.threads = duo ? 128 : 64;     // duo: two waves, the upper and the lower half of the tile
             o.tw = o.runs * 32;
             o.plw = o.runs + 2;
             o.prw = o.runs + (o.nl * ds + 31) / 32 + 4;
@@ -551,15 +552,25 @@ int sm_match_configure(sm_plan *plan)
         rows_words_o = rows_words;
         o.tiles_x = ceil_div(W, o.tw);
         const bool fulld = o.nl * ds == D;
-        const void *kfn = bs ? sm_bs_kernel_ptr(o.n, ds, fulld, ghost, false) : tiled_kernel_ptr(kernel, fulld, ghost);
+        const void *kfn = bs ? sm_bs_kernel_ptr(o.n, ds, fulld, ghost, false, duo) : tiled_kernel_ptr(kernel, fulld, ghost);
         const double wps = o.threads / 256.0;            // waves per SIMD per workgroup
         // warm-up rows are cheaper than output rows (no arg-max, no output); the constant is
         // the per-workgroup overhead (staging, lane set-up) in output-row units.  Refit on
         // same-device tile-height sweeps (tools/tune_tile_h.py, C2 / C3 / C4 x 8).
-        const double warm = bs ? 0.42 * (o.n - 1) + 1.8 : 0.4 * (o.n - 1) + 1.0;
+        // (duo: half the window rows + 1, and the exchange of the partial sums)
+        const double warm = duo ? 0.42 * (o.half + 1) + 2.3
+                          : bs ? 0.42 * (o.n - 1) + 1.8 : 0.4 * (o.n - 1) + 1.0;
         // lane-row work relative to ds = 16: the per-row shared views and one more merge level
         const double work = ds == 16 ? 1.0 : 0.5 * 1.10;
-        auto lds_of = [&](int th) { return (th + o.n - 1) * rows_words * 4; };
+        // duo: 2 * th rows per workgroup, and behind the staged rows the exchange block
+        // [2 buffers][2 waves][SB plane pairs][64 lanes] of 8 bytes
+        int sb = 0;
+        while ((1 << sb) <= o.n * o.n) sb++;
+        const int rows_per_wg = duo ? 2 : 1;
+        auto lds_of = [&](int th) {
+            const int staged = (rows_per_wg * th + o.n - 1) * rows_words * 4;
+            return duo ? ((staged + 7) & ~7) + 2 * 2 * sb * 64 * 8 : staged;
+        };
         int th = 0;
         double best_cost = 0;
         for (int c = 2; c <= 256; c++) {
@@ -570,7 +581,7 @@ int sm_match_configure(sm_plan *plan)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, o.threads, lds_of(cand)) != hipSuccess
                 || per_cu < 1)
                 per_cu = 1;
-            const long long tiles = (long long)o.tiles_x * ceil_div(H, cand) * plan->max_pairs;
+            const long long tiles = (long long)o.tiles_x * ceil_div(H, rows_per_wg * cand) * plan->max_pairs;
             const long long slots = (long long)cus * per_cu;
             double cost = 0;
             for (long long left = tiles; left > 0; left -= slots) {
@@ -590,9 +601,9 @@ int sm_match_configure(sm_plan *plan)
         if (th_env > 0) th = std::min(th_env, H);
         while (lds_of(th) > 64 * 1024 && th > 1) th--;
         o.tile_h = th;
-        o.tiles_y = ceil_div(H, th);
-        o.nsr = th + o.n - 1;
-        o.lds_bytes = o.nsr * rows_words * 4;
+        o.tiles_y = ceil_div(H, rows_per_wg * th);
+        o.nsr = rows_per_wg * th + o.n - 1;
+        o.lds_bytes = lds_of(th);
         // A grid that fits the chip in one round must also be SPREAD evenly: where the
         // registers allow more resident workgroups than the round needs (7x7: 3 waves
         // per SIMD, 2 needed) the dispatcher may stack 3 waves on some SIMDs and leave
@@ -606,7 +617,7 @@ int sm_match_configure(sm_plan *plan)
         if (bs) {
             const long long tiles = (long long)o.tiles_x * o.tiles_y * plan->max_pairs;
             const int cap = (int)((tiles + cus - 1) / cus);
-            const void *kcap = sm_bs_kernel_ptr(o.n, ds, fulld, ghost, true);
+            const void *kcap = sm_bs_kernel_ptr(o.n, ds, fulld, ghost, true, duo);
             const void *kuse = kfn;
             if (kcap && cap <= 8 && !getenv("SM_NO_CAP2")) { o.cap2 = 1; kuse = kcap; }
             int per_cu = 0;
@@ -622,7 +633,7 @@ int sm_match_configure(sm_plan *plan)
             }
         }
         o.ext_words = (o.tiles_x - 1) * (o.tw / 32) + o.prw;
-        o.ext_rows = o.tiles_y * th + o.n - 1;
+        o.ext_rows = o.tiles_y * rows_per_wg * th + o.n - 1;
         o.ext_image_words = (long long)o.ext_words * o.ext_rows;
         o.vec_ok = (W % 4) == 0;
         return best_cost;
@@ -634,6 +645,30 @@ int sm_match_configure(sm_plan *plan)
     int ds = 16;
     MatchGeom gsel;
     int rws = 0;
+    // Two-wave workgroups with a shared warm-up (k_match_bs<..., DUO>): HALF + 1 warm-up rows
+    // per wave instead of N, for an exchange through LDS.  Measured on one device at the same
+    // tile height (tools/ab_duo.sh): C3 95.3 -> 92.1 us, C4 x 8 83.6 -> 80.5, C5 197.9 -> 185.9,
+    // C2 20.5 -> 19.4, 21 x 21 at 4K 88.5 -> 77.4, C1 9.9 -> 10.0: taken wherever the cost
+    // model says so (SM_DUO=0/1 overrides: tuning, tests).
+    int duo_env = -1;
+    if (const char *e = getenv("SM_DUO")) duo_env = atoi(e) != 0;
+    auto duo_built = [&](int d) {
+        int l2;
+        return sm_bs_kernel_ptr(g.n, d, nl_for(d, l2) * d == D, ghost, false, true) != nullptr;
+    };
+    // lower-cost geometry of the two workgroup shapes for `d` shifts per lane
+    auto configure_best = [&](int d, MatchGeom &o, int &r) -> double {
+        const bool can = bs && duo_built(d);
+        double c1 = 0, c2 = 0;
+        MatchGeom o2;
+        int r2 = 0;
+        if (!(can && duo_env == 1)) c1 = configure(d, o, r, false);
+        if (can && duo_env != 0) {
+            c2 = configure(d, o2, r2, true);
+            if (duo_env == 1 || c2 < c1) { o = o2; r = r2; return c2; }
+        }
+        return c1;
+    };
     if (bs) {
         ds = sm_bs_default_ds(g.n);
         int l2;
@@ -649,11 +684,11 @@ int sm_match_configure(sm_plan *plan)
             // configurations stay at 16).
             MatchGeom g16, g8;
             int r16 = 0, r8 = 0;
-            const double c16 = configure(16, g16, r16), c8 = configure(8, g8, r8);
+            const double c16 = configure_best(16, g16, r16), c8 = configure_best(8, g8, r8);
             if (c8 < 0.95 * c16) ds = 8;
         }
     }
-    configure(ds, gsel, rws);
+    configure_best(ds, gsel, rws);
     g = gsel;
 
     snprintf(plan->describe, sizeof plan->describe,
@@ -662,8 +697,8 @@ int sm_match_configure(sm_plan *plan)
              bs ? "bit-sliced kernel" : kernel == SM_KERNEL_A ? "tiled kernel A"
                 : kernel == SM_KERNEL_B ? "tiled kernel B" : "tiled kernel C",
              g.n, D, ghost ? "ghost" : "toroidal",
-             g.tw, g.tile_h, g.threads, g.runs, g.nl, g.ds, g.tiles_x, g.tiles_y, g.lds_bytes,
-             g.cap2 ? ", 2 waves/SIMD variant" : "", g.ext_words, g.ext_rows);
+             g.tw, g.duo ? 2 * g.tile_h : g.tile_h, g.threads, g.runs, g.nl, g.ds, g.tiles_x, g.tiles_y, g.lds_bytes,
+             g.duo ? ", two-wave workgroups" : g.cap2 ? ", 2 waves/SIMD variant" : "", g.ext_words, g.ext_rows);
     return SM_OK;
 }
 

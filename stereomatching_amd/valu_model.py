@@ -1,13 +1,14 @@
 """Analytic VALU instruction count of one match launch.
 
-The bit-sliced kernel (csrc/sm_match_bs.hip) runs one wave per workgroup, and
+The bit-sliced kernel (csrc/sm_match_bs_kernel.h) runs one wave per workgroup --
+or two that share their warm-up rows ("duo", a variant of its own here) -- and
 every wave executes the same straight-line code per row: a fixed set-up
 (staging, lane roles, the N warm-up rows of its tile) and then one loop
 iteration per output row (sliding update of all sums, arg-max over the lane's
 shifts, merge across the shift lanes, planes -> integers).  So
 
     wave-instructions(launch) = waves * A  +  B * sum over waves of rows_out
-                              = tiles_x * tiles_y * pairs * A + B * tiles_x * H * pairs
+                              = waves_per_workgroup * tiles_x * tiles_y * pairs * A + B * tiles_x * H * pairs
 
 with two coefficients per kernel variant.  They are FITTED to SQ_INSTS_VALU of
 separate `rocprofv3 --pmc` passes at several tile heights
@@ -26,15 +27,17 @@ COUNTS = Path(__file__).resolve().parent / "valu_counts.json"
 
 def variant_key(geom: dict, num_shifts: int, border: int, want_best: bool) -> str:
     fulld = geom["shift_lanes"] * geom["shifts_per_lane"] == num_shifts
+    duo = ":duo" if geom["kernel"] == 4 and geom.get("waves_per_workgroup", 1) == 2 else ""
     return (f"k{geom['kernel']}:n{geom['window']}:ds{geom['shifts_per_lane']}:nl{geom['shift_lanes']}:"
-            f"{'ghost' if border else 'toroidal'}:fulld{int(fulld)}:best{int(bool(want_best))}")
+            f"{'ghost' if border else 'toroidal'}:fulld{int(fulld)}:best{int(bool(want_best))}{duo}")
 
 
 def waves_and_rows(geom: dict, height: int, pairs: int):
     """(waves of the launch, sum over waves of the output rows each produces)."""
-    waves_per_wg = max(1, geom["threads"] // 64)
+    waves_per_wg = geom.get("waves_per_workgroup") or max(1, geom["threads"] // 64)
     waves = geom["tiles_x"] * geom["tiles_y"] * pairs * waves_per_wg
-    rows = geom["tiles_x"] * height * pairs * waves_per_wg
+    # bit-sliced kernel: a wave owns rows of its own; the popcount kernels' waves share a tile's rows
+    rows = geom["tiles_x"] * height * pairs * (1 if geom["kernel"] == 4 else waves_per_wg)
     return waves, rows
 
 

@@ -293,8 +293,9 @@ def test_baseline_config_c4_batch_full_size(hip, mode):
     left, right = np.stack(ls), np.stack(rs)
     plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
     g = plan.geometry()
-    assert g["kernel"] == 4 and g["two_wave_variant"] == 1, plan.describe()   # bit-sliced, CAP2
-    assert g["tiles_x"] * g["tiles_y"] * pairs <= 2048, plan.describe()        # one round of the chip
+    # bit-sliced, at most two waves per SIMD: the capped one-wave build or two-wave workgroups
+    assert g["kernel"] == 4 and (g["two_wave_variant"] == 1 or g["waves_per_workgroup"] == 2), plan.describe()
+    assert g["tiles_x"] * g["tiles_y"] * pairs * g["waves_per_workgroup"] <= 2048, plan.describe()   # one round
     web, best = plan.run(dev(left), dev(right), 0.15, want_best=True)
     web_h, best_h = host(web), host(best)
     for j in range(pairs):
@@ -368,22 +369,75 @@ def env(monkeypatch):
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 @pytest.mark.parametrize("w,h,d,sw", [(300, 150, 128, 9), (71, 53, 30, 5), (130, 70, 64, 7), (90, 61, 64, 11)])
 @pytest.mark.parametrize("variant", [dict(SM_KERNEL="popcount"), dict(SM_DS=8), dict(SM_TILE_H=5),
-                                     dict(SM_DS=8, SM_TILE_H=7), dict(SM_NO_CAP2=1)])
+                                     dict(SM_DS=8, SM_TILE_H=7), dict(SM_NO_CAP2=1),
+                                     dict(SM_DUO=0), dict(SM_DUO=0, SM_TILE_H=5), dict(SM_DUO=0, SM_DS=8),
+                                     dict(SM_DUO=1, SM_TILE_H=5), dict(SM_DUO=1, SM_DS=8, SM_TILE_H=7)])
 def test_alternative_kernels_match_oracle(hip, env, variant, mode, w, h, d, sw):
     """the popcount kernels (general fallback), the 8-shifts-per-lane bit-sliced
     variant and odd tile heights give the same bits as the default path"""
     env(**variant)
     le, re = rand_edges(w, h, seed=w + d)
     best, web, desc = hip_hot_path(hip, le, re, d, sw, mode)
+    if "SM_DUO" in variant:
+        assert ("two-wave workgroups" in desc) == bool(variant["SM_DUO"]), desc
     if "SM_KERNEL" in variant:
         assert "tiled kernel" in desc
     elif "SM_DS" in variant and sw in (8, 9):       # the 8-per-lane variant is built for 9x9
         assert "lanes of 8" in desc
     elif "SM_NO_CAP2" in variant:                   # small grids default to the 2-wave variant
         assert "2 waves/SIMD variant" not in desc
-    elif "SM_TILE_H" in variant and sw in (5, 7) and "SM_DS" not in variant:
+    elif variant.get("SM_DUO") == 0 and "SM_TILE_H" in variant and sw in (5, 7) and "SM_DS" not in variant:
         assert "2 waves/SIMD variant" in desc
     obest, oweb = oracle.hot_path(le, re, d, sw, mode)
+    assert np.array_equal(web[0], oweb), desc
+    assert np.array_equal(best[0], obest), desc
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("sw,d", [(3, 16), (5, 30), (7, 64), (9, 128), (11, 100), (13, 24), (17, 64), (21, 30)])
+@pytest.mark.parametrize("h,tile_h", [(1, 4), (2, 4), (3, 2), (9, 4), (16, 4), (17, 4), (23, 3), (40, 16), (57, 8)])
+def test_two_wave_workgroups_match_oracle(hip, env, mode, sw, d, h, tile_h):
+    """k_match_bs<..., DUO>: the workgroup's two waves slide away from the tile's middle row
+    and swap half of their first window through LDS.  Every window that is built, image
+    heights around the tile boundaries (the last workgroup's lower wave with no rows at all,
+    with some, with all; images shorter than one tile), both borders,
+    shift counts that fill the lanes and that do not."""
+    env(SM_DUO=1, SM_TILE_H=tile_h)
+    w = 100 + 3 * sw
+    h = max(h, sw)              # the reference's rule: the window must fit the image
+    le, re = rand_edges(w, h, seed=h * 31 + sw)
+    best, web, desc = hip_hot_path(hip, le, re, d, sw, mode)
+    assert "two-wave workgroups" in desc, desc
+    obest, oweb = oracle.hot_path(le, re, d, sw, mode)
+    assert np.array_equal(web[0], oweb), desc
+    assert np.array_equal(best[0], obest), desc
+
+
+BUILT_BS = [(n, 16) for n in (3, 5, 7, 9, 11)] + [(n, 8) for n in range(3, 22, 2)]
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("fulld", [True, False])
+@pytest.mark.parametrize("shape", [dict(SM_DUO=0), dict(SM_DUO=0, SM_NO_CAP2=1), dict(SM_DUO=1)])
+@pytest.mark.parametrize("n,ds", BUILT_BS)
+def test_every_built_kernel_matches_oracle(hip, env, n, ds, shape, fulld, mode):
+    """Every instantiation of k_match_bs the library holds -- window x shifts per lane x
+    {shift range fills the lanes, does not} x border x {one wave, one wave capped at two
+    per SIMD, two-wave workgroups} -- on tiles of 4 rows, i.e. with three slides per wave:
+    the rows whose window rows come through the prefetched LDS reads.  (Round 2 found the
+    two largest ghost windows wrong from the third row of a tile on -- registers spilled
+    between an inline-asm read and its wait -- while every test used the default tile
+    height of 2 rows that such small images get.)"""
+    env(SM_DS=ds, SM_TILE_H=4, **shape)
+    d = 2 * ds if fulld else 2 * ds - 3
+    w, h = 150, n + 10
+    le, re = rand_edges(w, h, seed=n * 100 + ds)
+    best, web, desc = hip_hot_path(hip, le, re, d, n, mode)
+    assert f"lanes of {ds})" in desc and f"x{8 if shape['SM_DUO'] else 4} px" in desc, desc
+    assert ("two-wave workgroups" in desc) == bool(shape["SM_DUO"]), desc
+    if "SM_NO_CAP2" in shape:
+        assert "2 waves/SIMD variant" not in desc, desc
+    obest, oweb = oracle.hot_path(le, re, d, n, mode)
     assert np.array_equal(web[0], oweb), desc
     assert np.array_equal(best[0], obest), desc
 

@@ -33,10 +33,10 @@ libs = {}
 entries = []
 for so in sorted((ROOT / "stereomatching_amd" / "variants").glob("*.so")):
     entries.append((so.stem, so, {}))
-    if os.environ.get("AB_ENVS"):          # e.g. AB_ENVS="SM_DS=8;SM_TILE_H=32"
+    if os.environ.get("AB_ENVS"):          # e.g. AB_ENVS="SM_DS=8;SM_DUO=1,SM_TILE_H=32"
         for spec in os.environ["AB_ENVS"].split(";"):
-            k, v = spec.split("=")
-            entries.append((f"{so.stem}@{spec}", so, {k: v}))
+            envs_of = dict(kv.split("=") for kv in spec.split(","))     # "A=1,B=2": both at once
+            entries.append((f"{so.stem}@{spec}", so, envs_of))
 for name_, so, envs in entries:
     for k, v in envs.items():
         os.environ[k] = v
@@ -48,6 +48,10 @@ for name_, so, envs in entries:
     assert lib.sm_plan_create(0, w, h, d, sw, 1 if mode == "ghost" else 0, pairs, C.byref(plan)) == 0
     assert lib.sm_find_edges(plan, L.data_ptr(), R.data_ptr(), 0.15, pairs, None, None, None) == 0
     libs[name_] = (lib, plan, dict(envs))
+    if os.environ.get("AB_DESCRIBE"):
+        lib.sm_plan_describe.restype = C.c_char_p
+        lib.sm_plan_describe.argtypes = [vp]
+        print(f"# {name_}: {lib.sm_plan_describe(plan).decode()}")
     for k in envs:
         os.environ.pop(k)
 torch.cuda.synchronize()
@@ -55,7 +59,12 @@ torch.cuda.synchronize()
 ref = None
 times = {k: [] for k in libs}
 for r in range(rounds + 1):
-    for name, (lib, plan, envs_) in libs.items():
+    # alternate the order: a launch is up to ~2 % faster behind launches of the SAME kernel
+    # shape than behind another one's, and a fixed order would credit that to one entry
+    order = list(libs.items())
+    if r % 2 == 0:
+        order.reverse()
+    for name, (lib, plan, envs_) in order:
         os.environ.update(envs_)           # some overrides are read at launch time
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
