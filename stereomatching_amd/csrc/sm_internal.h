@@ -57,6 +57,7 @@ struct MatchGeom {
     int lds_bytes;
     int cap2;            // bit-sliced kernel: launch the two-waves-per-SIMD variant
     int duo;             // bit-sliced kernel: two-wave workgroups of 2 * tile_h rows (shared warm-up)
+    unsigned prio_pattern;   // bit-sliced kernel: the time-sliced priority schedule (sm_match_bs_kernel.h)
     int web_bytes;       // bytes per element of the web map of THIS launch: 4 (int32), 2, 1
 };
 
@@ -134,6 +135,7 @@ int sm_fail(int code, const char *fmt, ...);
 // sm_match_bs.hip (bit-sliced kernel; nullptr if not built for this window)
 const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost, bool cap2, bool duo = false);
 int sm_bs_default_ds(int n);
+unsigned sm_bs_default_pattern(bool duo);
 int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);
 int sm_bs_prepare(sm_plan *plan);        // set-up launch: code object loaded before the first real one
 

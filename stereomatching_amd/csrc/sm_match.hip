@@ -505,6 +505,7 @@ int sm_match_configure(sm_plan *plan)
         g.ext_image_words = (long long)g.ext_words * g.ext_rows;
         g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = g.ds = 0;
         g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = g.cap2 = g.duo = 0;
+        g.prio_pattern = 0;
         snprintf(plan->describe, sizeof plan->describe,
                  "generic kernel (n=%d, D=%d): 1 lane/pixel, direct window sums", g.n, D);
         return SM_OK;
@@ -563,13 +564,13 @@ int sm_match_configure(sm_plan *plan)
         // lane-row work relative to ds = 16: the per-row shared views and one more merge level
         const double work = ds == 16 ? 1.0 : 0.5 * 1.10;
         // duo: 2 * th rows per workgroup, and behind the staged rows the exchange block
-        // [2 buffers][2 waves][SB plane pairs][64 lanes] of 8 bytes
+        // [2 halves of the shifts][ds / 2 * SB / 2 plane pairs][64 lanes] of 8 bytes
         int sb = 0;
         while ((1 << sb) <= o.n * o.n) sb++;
         const int rows_per_wg = duo ? 2 : 1;
         auto lds_of = [&](int th) {
             const int staged = (rows_per_wg * th + o.n - 1) * rows_words * 4;
-            return duo ? ((staged + 7) & ~7) + 2 * 2 * sb * 64 * 8 : staged;
+            return duo ? ((staged + 7) & ~7) + ds * sb * 256 : staged;
         };
         int th = 0;
         double best_cost = 0;
@@ -690,6 +691,8 @@ int sm_match_configure(sm_plan *plan)
     }
     configure_best(ds, gsel, rws);
     g = gsel;
+    g.prio_pattern = sm_bs_default_pattern(g.duo != 0);
+    if (const char *e = getenv("SM_PATTERN")) g.prio_pattern = (unsigned)strtoul(e, nullptr, 16);   // tuning
 
     snprintf(plan->describe, sizeof plan->describe,
              "%s (n=%d, D=%d, %s): tile %dx%d px, %d threads "

@@ -60,6 +60,13 @@ int sm_bs_default_ds(int n)
     return 0;
 }
 
+// the time-sliced priority schedule of the kernel (SM_BS_PATTERN in sm_match_bs_kernel.h)
+unsigned sm_bs_default_pattern(bool duo)
+{
+    (void)duo;
+    return SM_BS_PATTERN;
+}
+
 // One launch of the plan's kernel that does nothing (web == nullptr): the runtime loads a
 // code object when a kernel of it is first LAUNCHED -- its code object is ~1-2 MB and
 // the first real launch otherwise waits ~130 us for it inside the caller's timed region.

@@ -62,8 +62,9 @@ int SM_BS_CAT(sm_bs_set_stamps_, SM_BS_TU)(void *buf)
 }
 #define SM_STAMP(slot)                                                                          \
     do {                                                                                        \
-        if (threadIdx.x == 0 && g_sm_stamps) {                                                  \
-            const size_t wg_ = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+        if ((threadIdx.x & 63) == 0 && g_sm_stamps) {        /* one record per WAVE */           \
+            const size_t wg_ = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) \
+                               * (blockDim.x >> 6) + (threadIdx.x >> 6);                        \
             g_sm_stamps[wg_ * 10 + 2 * (slot)] = __builtin_amdgcn_s_memrealtime();              \
             g_sm_stamps[wg_ * 10 + 2 * (slot) + 1] = __builtin_amdgcn_s_memtime();              \
             if ((slot) == 0)                                                                    \
@@ -414,6 +415,8 @@ __device__ __forceinline__ void addsub_lockstep(u32 (&S)[DS][SB], int dd0, const
     }
 }
 
+template <int V> struct IntTag { static constexpr int value = V; };
+
 template <int CTRL>
 __device__ __forceinline__ u32 dpp(u32 v)
 {
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
 #define SM_SLICE_PRIO()                                                               \
     do {                                                                              \
         const unsigned unit_ = (unsigned)((clk - clk0) >> 14) & 31u;                  \
-        if ((((unsigned)SM_BS_PATTERN >> unit_) ^ slot_parity) & 1) __builtin_amdgcn_s_setprio(3); \
+        if (((g.prio_pattern >> unit_) ^ slot_parity) & 1) __builtin_amdgcn_s_setprio(3);  \
         else __builtin_amdgcn_s_setprio(0);                                           \
     } while (0)
 #else
@@ -745,36 +748,57 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
 #pragma unroll 1
         for (int e = 0; e <= HALF; e++) {
         if (e == HALF) {
-        // ... the other wave's half: CH shifts at a time through a double-buffered LDS block
-        // [buffer][wave][CH * SB / 2 plane pairs][64 lanes] (one barrier per chunk: a wave
-        // overwrites a buffer two chunks later, behind the barrier that its partner reaches
-        // only after having read it)
-        constexpr int CH = 2, XP = CH * SB / 2;
-        static_assert(DS % CH == 0 && (CH * SB) % 2 == 0, "exchange chunks");
+        // ... the other wave's half, through an LDS block [2 halves of the shifts][DS / 2 *
+        // SB / 2 plane pairs][64 lanes]: wave w assembles the totals of half w.  Each wave
+        // (1) writes its partial sums of the OTHER half, (2) adds the partner's partial sums
+        // of its own half to its own and writes the totals back to the same words, (3) reads
+        // the totals of the other half -- two barriers.  (A first version swapped two shifts
+        // at a time, both ways, with a barrier each: 8 barriers, each of which waits for
+        // whichever of the two waves its SIMD currently serves at the lower priority --
+        // measured ~2.3 us per workgroup, more than one of the 1.7 us warm-up rows saved.)
+        constexpr int DH = DS / 2, XP = DH * SB / 2;
+        static_assert(DS % 2 == 0 && (DH * SB) % 2 == 0, "exchange halves");
         typedef u32 v2u __attribute__((ext_vector_type(2)));
-        v2u *xq = reinterpret_cast<v2u *>(lds + ((nsr * (plw + prw) + 1) & ~1));
-#pragma unroll
-        for (int c = 0; c < DS / CH; c++) {
-            v2u *mine = xq + (((c & 1) * 2 + wv) * XP) * 64 + tid;
-            const v2u *other = xq + (((c & 1) * 2 + (1 - wv)) * XP) * 64 + tid;
+        v2u *xq = reinterpret_cast<v2u *>(lds + ((nsr * (plw + prw) + 1) & ~1)) + tid;
+        auto exchange = [&](auto own_tag) {
+            constexpr int OWN = decltype(own_tag)::value, OTH = 1 - OWN;
+            v2u *slot_own = xq + OWN * XP * 64, *slot_oth = xq + OTH * XP * 64;
 #pragma unroll
             for (int j = 0; j < XP; j++) {
                 const int p = 2 * j, q = 2 * j + 1;
-                const v2u v = {S[c * CH + p / SB][p % SB], S[c * CH + q / SB][q % SB]};
-                mine[j * 64] = v;
+                const v2u v = {S[OTH * DH + p / SB][p % SB], S[OTH * DH + q / SB][q % SB]};
+                slot_oth[j * 64] = v;
             }
             __syncthreads();
-            u32 o[CH][SB];
+#pragma unroll
+            for (int dd = 0; dd < DH; dd += 2) {        // two shifts = SB plane pairs at a time
+                u32 o[2][SB];
+#pragma unroll
+                for (int j = 0; j < SB; j++) {
+                    const int p = 2 * j, q = 2 * j + 1;
+                    const v2u v = slot_own[(dd * SB / 2 + j) * 64];
+                    o[p / SB][p % SB] = v.x;
+                    o[q / SB][q % SB] = v.y;
+                }
+                add_planes<SB, SB>(S[OWN * DH + dd], o[0]);
+                add_planes<SB, SB>(S[OWN * DH + dd + 1], o[1]);
+#pragma unroll
+                for (int j = 0; j < SB; j++) {
+                    const int p = 2 * j, q = 2 * j + 1;
+                    const v2u v = {S[OWN * DH + dd + p / SB][p % SB], S[OWN * DH + dd + q / SB][q % SB]};
+                    slot_own[(dd * SB / 2 + j) * 64] = v;
+                }
+            }
+            __syncthreads();
 #pragma unroll
             for (int j = 0; j < XP; j++) {
                 const int p = 2 * j, q = 2 * j + 1;
-                const v2u v = other[j * 64];
-                o[p / SB][p % SB] = v.x;
-                o[q / SB][q % SB] = v.y;
+                const v2u v = slot_oth[j * 64];
+                S[OTH * DH + p / SB][p % SB] = v.x;
+                S[OTH * DH + q / SB][q % SB] = v.y;
             }
-#pragma unroll
-            for (int dd = 0; dd < CH; dd++) add_planes<SB, SB>(S[c * CH + dd], o[dd]);
-        }
+        };
+        if (wv) exchange(IntTag<1>{}); else exchange(IntTag<0>{});
         }
         // ... and (e == HALF) the one row only this wave's first window has
         slide_in(c0 + sgn * e);

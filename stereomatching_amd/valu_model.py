@@ -41,6 +41,14 @@ def waves_and_rows(geom: dict, height: int, pairs: int):
     return waves, rows
 
 
+def _setup_text(geom: dict) -> str:
+    n = geom["window"]
+    if geom["kernel"] == 4 and geom.get("waves_per_workgroup", 1) == 2:
+        return (f"set-up + {n // 2 + 1} warm-up rows + swap of the {n - 1} shared rows' sums with the "
+                f"workgroup's other wave")
+    return f"set-up + {n} warm-up rows"
+
+
 def match_launch(geom: dict, width: int, height: int, num_shifts: int, border: int,
                  pairs: int, want_best: bool = False):
     if not COUNTS.exists():
@@ -54,7 +62,7 @@ def match_launch(geom: dict, width: int, height: int, num_shifts: int, border: i
     total = c["per_wave"] * waves + c["per_wave_row"] * rows
     return {
         "wave_instructions": int(round(total)),
-        "model": f"{waves} waves x {c['per_wave']:.0f} (set-up + {geom['window']} warm-up rows) + "
+        "model": f"{waves} waves x {c['per_wave']:.0f} ({_setup_text(geom)}) + "
                  f"{rows} wave-rows x {c['per_wave_row']:.0f}",
         "source": f"{table.get('source', 'valu_counts.json')}; fit residual <= "
                   f"{c.get('max_rel_residual', 0) * 100:.2f} % over tile heights "

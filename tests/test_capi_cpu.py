@@ -79,17 +79,22 @@ def test_synth_and_pgm_roundtrip(tmp_path):
 
 def test_valu_model_reproduces_the_profiled_count():
     """The analytic VALU model behind bench.py's roofline: for the headline geometry (C3: 15 x
-    135 one-wave tiles of 16 rows) it must land on the SQ_INSTS_VALU the r02 profile holds,
-    and every fitted variant must have kept its residual small."""
+    68 two-wave workgroups of 2 x 16 rows) it must land on the SQ_INSTS_VALU the r02 profile
+    holds, and every fitted variant must have kept its residual small."""
     import json
     from pathlib import Path
 
     from stereomatching_amd import valu_model
     root = Path(__file__).resolve().parent.parent
-    geom = dict(kernel=4, window=9, shifts_per_lane=16, shift_lanes=8, threads=64, tile_w=256, tile_h=16,
-                tiles_x=15, tiles_y=135)
+    geom = dict(kernel=4, window=9, shifts_per_lane=16, shift_lanes=8, threads=128, tile_w=256, tile_h=32,
+                tiles_x=15, tiles_y=68, waves_per_workgroup=2)
     m = valu_model.match_launch(geom, 3840, 2160, 128, 0, 1, want_best=False)
-    assert m is not None and m["variant"] == "k4:n9:ds16:nl8:toroidal:fulld1:best0"
+    assert m is not None and m["variant"] == "k4:n9:ds16:nl8:toroidal:fulld1:best0:duo"
+    # the one-wave shape of the same window (SM_DUO=0) is a variant of its own
+    one = valu_model.match_launch(dict(geom, threads=64, tile_h=16, tiles_y=135, waves_per_workgroup=1),
+                                  3840, 2160, 128, 0, 1)
+    assert one["variant"] == "k4:n9:ds16:nl8:toroidal:fulld1:best0"
+    assert one["wave_instructions"] > 1.05 * m["wave_instructions"]      # 9 warm-up rows per wave, not 5
     prof = json.loads((root / "profiles" / "r02" / "pmc_summary.json").read_text())
     counted = [v["SQ_INSTS_VALU"] for k, v in prof.items() if k.startswith("k_match_bs<9, 16")][0]
     assert abs(m["wave_instructions"] - counted) / counted < 0.005

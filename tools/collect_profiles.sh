@@ -7,7 +7,7 @@
 # trace domains), as the pool requires.
 set -u
 TAG=${1:-r01}
-ARGS=${2:---steps 20 --warmup 5 --no-cpu-baseline}
+ARGS=${2:---steps 20 --warmup 5 --no-cpu-baseline --no-e2e}
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 rm -rf "$OUT"   # gpurun merges results into the build box's copy: delete that one too before a re-run

@@ -35,7 +35,7 @@ print(plan.describe())
 ls, rs = zip(*[make_pair(w, h, d, seed=j) for j in range(pairs)])
 left, right = torch.from_numpy(np.stack(ls)).cuda(), torch.from_numpy(np.stack(rs)).cuda()
 plan.find_all_edges(left, right, want_edges=False)
-n_wg = g["tiles_x"] * g["tiles_y"] * pairs
+n_wg = g["tiles_x"] * g["tiles_y"] * pairs * (g["waves_per_workgroup"] if g["kernel"] == 4 else 1)   # records: one per wave
 stamps = torch.zeros((n_wg, 10), dtype=torch.int64, device="cuda")
 web = None
 for _ in range(5):                       # warm: clocks, code object
