@@ -60,8 +60,16 @@ def _compile_and_link(out: Path, objdir: Path, flags=(), verbose: bool = False, 
     objdir.mkdir(parents=True, exist_ok=True)
     common = [*HIPCC_FLAGS, *flags, f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 
+    stamp = objdir / "flags.txt"          # objects of another flag set are not reused
+    if not stamp.exists() or stamp.read_text() != " ".join(common):
+        for old in objdir.glob("*.o"):
+            old.unlink()
+        stamp.write_text(" ".join(common))
+
     def one(src: str) -> Path:
         obj = objdir / (Path(src).stem + ".o")
+        if not _stale(obj, [CSRC / src, *HEADERS]):
+            return obj
         cmd = [_hipcc(), *common, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -125,7 +133,8 @@ def build_host(verbose: bool = False) -> None:
     """The C command-line programs (stereopar, stereopar-ghost, ...)."""
     out = None if verbose else subprocess.DEVNULL
     if (ROOT / "Makefile").exists():
-        subprocess.check_call(["make", "-C", str(ROOT), "build=timing"], stdout=out)
+        # (shares stereomatching_amd/obj/product with build_hip: the library is not compiled twice)
+        subprocess.check_call(["make", "-C", str(ROOT), f"-j{_jobs()}", "build=timing"], stdout=out)
 
 
 if __name__ == "__main__":
