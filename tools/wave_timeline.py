@@ -105,6 +105,26 @@ for rep in range(3):
             ph_cy = [np.median(cko[idx, k + 1] - cko[idx, k]) for k in range(3)]
             print(f"    {name:8s} wave: stage {ph_us[0]:6.2f} us / warm-up {ph_us[1]:6.2f} us ({ph_cy[1]:9.0f} cyc)"
                   f" / rows {ph_us[2]:6.2f} us ({ph_cy[2]:9.0f} cyc)")
+    # lifetime by hardware wave slot, and (two-wave workgroups) where a workgroup's waves sit
+    ok = rt[:, 3] > 0
+    for sl in np.unique(slot):
+        m = (slot == sl) & ok
+        print(f"    slot {int(sl)}: waves {int(m.sum())}, lifetime median {np.median(life[m]):.1f} us, "
+              f"start median {np.median(rt[m, 0]):.2f} us")
+    wpw = g["waves_per_workgroup"] if g["kernel"] == 4 else 1
+    if wpw == 2:
+        s0, s1 = slot[0::2], slot[1::2]
+        print("  slots of a workgroup's (wave 0, wave 1):",
+              {(int(a_), int(b_)): int(((s0 == a_) & (s1 == b_)).sum()) for a_ in np.unique(s0) for b_ in np.unique(s1)})
+        print("  same CU:", int((key[0::2] == key[1::2]).sum()), "of", len(s0),
+              " SIMDs (wave 0, wave 1):",
+              {(int(a_), int(b_)): int(((simd[0::2] == a_) & (simd[1::2] == b_)).sum()) for a_ in range(4) for b_ in range(4)
+               if ((simd[0::2] == a_) & (simd[1::2] == b_)).any()})
+        wg_lin = np.arange(len(s0))
+        for sl in np.unique(s0):
+            m = s0 == sl
+            print(f"    workgroups whose wave 0 is in slot {int(sl)}: {int(m.sum())}, linear index pct "
+                  f"{np.percentile(wg_lin[m], [0, 10, 50, 90, 100]).round(0)}")
     single = np.flatnonzero(np.isin(simd_key, uniq[cnt == 1]))
     if len(single):
         print(f"  waves alone on their SIMD: {len(single)}, lifetime median {np.median(life[single]):.1f} us")
