@@ -281,6 +281,27 @@ def test_baseline_config_4k_full_image_vs_oracle(hip, cfg):
     plan.close()
 
 
+@pytest.mark.parametrize("mode,d,sw", [("toroidal", 128, 9), ("ghost", 48, 9)])
+def test_largest_image_8k_full_image_vs_oracle(hip, mode, d, sw):
+    """Four times the largest BASELINE image: 7680 x 4320, every pixel of edges, web and best
+    against the oracle -- 64-row tiles (the plan keeps the grid at one round of the chip), 30
+    tile columns, and in the ghost case a shift count that does not fill the shift lanes."""
+    w, h = 7680, 4320
+    left, right = make_pair(w, h, d, seed=5)
+    plan = hip.StereoPlan(w, h, d, sw, mode)
+    g = plan.geometry()
+    assert g["kernel"] == 4 and g["tiles_x"] == (30 if d == 128 else 15), plan.describe()
+    el, er = plan.find_all_edges(dev(left), dev(right), 0.15)
+    web, best = plan.match_wta(1)
+    oel = oracle.find_all_edges_banded(left, 0.15, mode)
+    oer = oracle.find_all_edges_banded(right, 0.15, mode)
+    assert np.array_equal(host(el)[0], oel) and np.array_equal(host(er)[0], oer)
+    ob, ow = oracle.hot_path_banded(oel, oer, d, sw, mode)
+    assert np.array_equal(host(web)[0], ow), plan.describe()
+    assert np.array_equal(host(best)[0], ob), plan.describe()
+    plan.close()
+
+
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 def test_baseline_config_c4_batch_full_size(hip, mode):
     """C4 as one GPU sees it: a batch of 8 x 1080p pairs, 64 shifts, 7x7, in ONE launch --
