@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_edges_ext(const u8 *__restrict__ src_l,
 #ifndef SM_EDGE4_ROWS
 #define SM_EDGE4_ROWS 4
 #endif
-template <bool GHOST, bool TABLES>
+template <bool GHOST, bool TABLES, bool STACKED = false>
 __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l,
                                                     const u8 *__restrict__ src_r,
                                                     u8 *__restrict__ edges_l,
@@ -338,8 +338,15 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
     constexpr int R = SM_EDGE4_ROWS;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int xe = (blockIdx.x * 256 + tid) * 4;          // first of this lane's 4 ext pixels
-    const int ye0 = blockIdx.y * R;
+    // The workgroup's four waves lie side by side in one strip or (STACKED) take four strips
+    // below each other, 256 ext pixels wide: the host picks the second where the round-up
+    // of a 1024-pixel workgroup along x would leave much of the launch idle (a 1080p ext row
+    // is 560 lanes: 9 waves instead of 12; 8 x 1080p: 40.8 -> 34.0 us; C5: 29.5 -> 26.1) and
+    // the first where a row is whole workgroups anyway (4K toroidal: 17.0 vs 18.1 us stacked).
+    // first of this lane's 4 ext pixels, first ext row of the wave's strip
+    const int xe = STACKED ? (blockIdx.x * 64 + lane) * 4 : (blockIdx.x * 256 + tid) * 4;
+    const int ye0 = STACKED ? (blockIdx.y * 4 + (tid >> 6)) * R : blockIdx.y * R;
+    if (STACKED && ye0 >= g.ext_rows) return;             // the round-up of the strips (wave-uniform)
     const int pair = blockIdx.z >> 1, side = blockIdx.z & 1;
     const size_t img = (size_t)pair * g.w * g.h;
     const u8 *src = (side ? src_r : src_l) + img;
@@ -461,11 +468,11 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
             *reinterpret_cast<u32 *>(edges + img + (size_t)y * g.w + x) = bytes;
         }
         // 8 lanes x 4 bits -> one ext word, OR-reduced within each group of 8 lanes
-        u32 wv = nib << (4 * (tid & 7));
+        u32 wv = nib << (4 * (lane & 7));
         wv |= (u32)__builtin_amdgcn_update_dpp(0, (int)wv, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
         wv |= (u32)__builtin_amdgcn_update_dpp(0, (int)wv, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
         wv |= (u32)__builtin_amdgcn_update_dpp(0, (int)wv, 0x141, 0xf, 0xf, true);   // row_half_mirror
-        if ((tid & 7) == 0 && wd < g.ext_words && row_ok) ext_img[(size_t)ye * g.ext_words + wd] = wv;
+        if ((lane & 7) == 0 && wd < g.ext_words && row_ok) ext_img[(size_t)ye * g.ext_words + wd] = wv;
 #pragma unroll
         for (int k = 0; k < 6; k++) { v[0][k] = v[1][k]; v[1][k] = v[2][k]; }
 #pragma unroll
@@ -839,6 +846,7 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
             (const void *)k_fill_holes_step, (const void *)k_count_zeros, (const void *)k_step3_init,
             (const void *)k_contour, (const void *)k_minmax_zero, (const void *)k_publish_flags,
             gh ? (const void *)k_edges_ext4<true, true> : (const void *)k_edges_ext4<false, true>,
+            gh ? (const void *)k_edges_ext4<true, true, true> : (const void *)k_edges_ext4<false, true, true>,
             gh ? (const void *)k_edges_ext<true, true> : (const void *)k_edges_ext<false, true>,
         };
         for (const void *f : fns) (void)hipFuncGetAttributes(&fa, f);
@@ -1003,12 +1011,23 @@ extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
     const bool aligned4 = (((uintptr_t)d_gray_left | (uintptr_t)d_gray_right |
                             (uintptr_t)d_edges_left | (uintptr_t)d_edges_right) & 3) == 0;
     if (g.w % 4 == 0 && aligned4 && !getenv("SM_EDGES1")) {
-        const dim3 grid4((g.ext_words * 8 + 255) / 256, (g.ext_rows + SM_EDGE4_ROWS - 1) / SM_EDGE4_ROWS,
-                         pairs * 2);
+        const int strips = (g.ext_rows + SM_EDGE4_ROWS - 1) / SM_EDGE4_ROWS;
+        const int lanes = g.ext_words * 8;
+        // waves side by side, unless that rounds the row up by more than 3 % (see the kernel)
+        const bool stacked = (lanes + 255) / 256 * 256 > lanes + lanes / 32;
+        const dim3 grid4 = stacked ? dim3((lanes + 63) / 64, (strips + 3) / 4, pairs * 2)
+                                   : dim3((lanes + 255) / 256, strips, pairs * 2);
 #define SM_EDGES_GO(G, T)                                                                      \
-    hipLaunchKernelGGL((k_edges_ext4<G, T>), grid4, block, 0, st, d_gray_left, d_gray_right,     \
-                       d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab, g, threshold, \
-                       edge_neg_t(threshold))
+    do {                                                                                       \
+        if (stacked)                                                                           \
+            hipLaunchKernelGGL((k_edges_ext4<G, T, true>), grid4, block, 0, st, d_gray_left, d_gray_right, \
+                               d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab, g, threshold,   \
+                               edge_neg_t(threshold));                                         \
+        else                                                                                   \
+            hipLaunchKernelGGL((k_edges_ext4<G, T, false>), grid4, block, 0, st, d_gray_left, d_gray_right, \
+                               d_edges_left, d_edges_right, plan->d_ext, plan->d_edge_tab, g, threshold,   \
+                               edge_neg_t(threshold));                                         \
+    } while (0)
         if (plan->tab_ok) { if (ghost) SM_EDGES_GO(true, true); else SM_EDGES_GO(false, true); }
         else              { if (ghost) SM_EDGES_GO(true, false); else SM_EDGES_GO(false, false); }
 #undef SM_EDGES_GO

@@ -647,7 +647,9 @@ def edges4_read_columns(w, g):
     neighbour byte (xn).  Mirrors csrc/sm_api.hip; the kernel must never read a column
     outside [0, w)."""
     ext_px = g["ext_words"] * 32
-    lanes = ((g["ext_words"] * 8 + 255) // 256) * 256
+    row = g["ext_words"] * 8
+    stacked = (row + 255) // 256 * 256 > row + row // 32       # the host's choice of block shape
+    lanes = (row + 63) // 64 * 64 if stacked else (row + 255) // 256 * 256
     lane = np.arange(lanes)
     xe = lane * 4
     x = xe - g["pad_l"]
