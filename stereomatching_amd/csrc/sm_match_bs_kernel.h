@@ -274,7 +274,8 @@ __device__ __forceinline__ void addsub_planes(u32 (&s)[SB], const u32 (&hn)[HB],
 #define SM_BS_SLICE 16    // swap every 65536 cycles (~31 us): 13 / 15 / 17 measured slower
 #endif
 #ifndef SM_BS_PATTERN
-#define SM_BS_PATTERN 0xF0F0F0F0u   // 4 units (65536 cycles) per slice; 2 / 3 / 6 units and the inverse measured
+#define SM_BS_PATTERN 0xF0F0F0F0u   // 4 units (65536 cycles) per slice; 2 / 3 / 5 / 6 units, shifted phases, unequal duty
+                                    // cycles and the inverse measured, for both workgroup shapes: all within +-1.5 %
 #endif
 #ifndef SM_BS_NOP
 #define SM_BS_NOP 3
@@ -505,8 +506,9 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
     unsigned long long clk = __builtin_amdgcn_s_memtime();
 #if SM_BS_PATTERN
     // slices counted from the wave's own start (the waves of a launch start within 0.5 us of
-    // each other): bit k of SM_BS_PATTERN says which slot parity is favoured during the
-    // k-th 16384-cycle unit, so the schedule is the same in every launch
+    // each other): bit k of the plan's pattern (g.prio_pattern: SM_BS_PATTERN unless SM_PATTERN
+    // in the environment overrides it for tuning) says which slot parity is favoured during
+    // the k-th 16384-cycle unit, so the schedule is the same in every launch
     const unsigned long long clk0 = clk;
 #define SM_SLICE_PRIO()                                                               \
     do {                                                                              \
