@@ -72,6 +72,15 @@ int sm_memcpy_h2d_async(int device, void *d_dst, const void *h_src, size_t bytes
 int sm_memcpy_d2h_async(int device, void *h_dst, const void *d_src, size_t bytes, void *stream);
 int sm_stream_create(int device, void **stream);
 int sm_stream_destroy(int device, void *stream);
+/* events order work ACROSS streams: a host that keeps uploads, kernels and downloads on three
+ * streams of their own (each copy direction then has a DMA queue to itself and the two
+ * directions of the link run at the same time) chains them with these.  sm_event_sync blocks
+ * the calling thread until the recorded work has finished.                                  */
+int sm_event_create(int device, void **event);
+int sm_event_destroy(int device, void *event);
+int sm_event_record(int device, void *event, void *stream);
+int sm_stream_wait_event(int device, void *stream, void *event);
+int sm_event_sync(int device, void *event);
 
 /* ---- plan: geometry + private workspace for one image size ------------- *
  * num_shifts  = the reference's compile-time NUM_SHIFTS (src/stereo.c:6),

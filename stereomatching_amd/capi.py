@@ -60,6 +60,11 @@ _SIGNATURES = {
     "sm_memcpy_d2h_async": (_int, [_int, _vp, _vp, _sz, _vp]),
     "sm_stream_create": (_int, [_int, C.POINTER(_vp)]),
     "sm_stream_destroy": (_int, [_int, _vp]),
+    "sm_event_create": (_int, [_int, C.POINTER(_vp)]),
+    "sm_event_destroy": (_int, [_int, _vp]),
+    "sm_event_record": (_int, [_int, _vp, _vp]),
+    "sm_stream_wait_event": (_int, [_int, _vp, _vp]),
+    "sm_event_sync": (_int, [_int, _vp]),
     "sm_plan_create": (_int, [_int, _int, _int, _int, _int, _int, _int, C.POINTER(_vp)]),
     "sm_plan_destroy": (None, [_vp]),
     "sm_plan_describe": (C.c_char_p, [_vp]),

@@ -772,6 +772,47 @@ extern "C" int sm_stream_destroy(int device, void *stream)
     return SM_OK;
 }
 
+extern "C" int sm_event_create(int device, void **event)
+{
+    if (!event) return sm_fail(SM_ERR_ARG, "sm_event_create: event is NULL");
+    SM_TRY(use_device(device));
+    hipEvent_t ev = nullptr;
+    SM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *event = (void *)ev;
+    return SM_OK;
+}
+
+extern "C" int sm_event_destroy(int device, void *event)
+{
+    SM_TRY(use_device(device));
+    SM_HIP(hipEventDestroy((hipEvent_t)event));
+    return SM_OK;
+}
+
+extern "C" int sm_event_record(int device, void *event, void *stream)
+{
+    if (!event) return sm_fail(SM_ERR_ARG, "sm_event_record: event is NULL");
+    SM_TRY(use_device(device));
+    SM_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return SM_OK;
+}
+
+extern "C" int sm_stream_wait_event(int device, void *stream, void *event)
+{
+    if (!event) return sm_fail(SM_ERR_ARG, "sm_stream_wait_event: event is NULL");
+    SM_TRY(use_device(device));
+    SM_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return SM_OK;
+}
+
+extern "C" int sm_event_sync(int device, void *event)
+{
+    if (!event) return sm_fail(SM_ERR_ARG, "sm_event_sync: event is NULL");
+    SM_TRY(use_device(device));
+    SM_HIP(hipEventSynchronize((hipEvent_t)event));
+    return SM_OK;
+}
+
 extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
                               int square_width, int border, int max_pairs, sm_plan **out)
 {

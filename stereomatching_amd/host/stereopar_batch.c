@@ -9,9 +9,12 @@
  * parameters and validation, same stages up to the web map -- and adds what
  * the reference does not have: pair j goes to device j mod n_devices (no
  * exchange between devices: pairs are independent), each device has its own
- * host thread, plans and streams; the images are decoded into one pinned arena
- * and uploaded straight from it; uploads, kernels and downloads of neighbouring
- * batches overlap (two slots in flight per device).  Results come back as NARROW web maps (uint8 when the shifts fit,
+ * host thread, plan and streams; the images are decoded into one pinned arena
+ * and uploaded straight from it; uploads, kernels and downloads run on a stream
+ * each (a DMA queue per copy direction: both directions of the link are busy at
+ * once), chained with events over three buffer sets, so that the upload of batch
+ * k+1, the kernels of batch k and the download of batch k-1 overlap.  Results
+ * come back as NARROW web maps (uint8 when the shifts fit,
  * else uint16: sm_run_typed), a quarter / half of the int32 PCIe traffic.
  *
  *   stereopar-batch [options] LIST [threshold] [square_width]
@@ -38,6 +41,9 @@
 #include "stereo_hip.h"
 
 #include <pthread.h>
+#ifdef __SSE2__
+#include <emmintrin.h>
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -49,7 +55,7 @@
 #define DEFAULT_THRESHOLD 0.15
 #define DEFAULT_SQUARE_WIDTH 21
 #define MAX_DEVICES 64
-#define SLOTS 2
+#define SLOTS 3
 
 typedef struct {
     char *left, *right;
@@ -139,6 +145,23 @@ static unsigned long long sum_bytes(const uint8_t *p, size_t n)
     const unsigned long long M = 0x00ff00ff00ff00ffULL;
     unsigned long long total = 0;
     size_t i = 0;
+#ifdef __SSE2__
+    /* x86-64: psadbw against zero sums 16 bytes per instruction into two 64-bit lanes */
+    {
+        __m128i acc = _mm_setzero_si128();
+        const __m128i zero = _mm_setzero_si128();
+        for (; i + 64 <= n; i += 64) {
+            const __m128i a = _mm_sad_epu8(_mm_loadu_si128((const __m128i *)(p + i)), zero);
+            const __m128i b = _mm_sad_epu8(_mm_loadu_si128((const __m128i *)(p + i + 16)), zero);
+            const __m128i c = _mm_sad_epu8(_mm_loadu_si128((const __m128i *)(p + i + 32)), zero);
+            const __m128i d = _mm_sad_epu8(_mm_loadu_si128((const __m128i *)(p + i + 48)), zero);
+            acc = _mm_add_epi64(acc, _mm_add_epi64(_mm_add_epi64(a, b), _mm_add_epi64(c, d)));
+        }
+        unsigned long long lanes[2];
+        _mm_storeu_si128((__m128i *)lanes, acc);
+        total = lanes[0] + lanes[1];
+    }
+#endif
     while (i + 8 <= n) {
         unsigned long long lanes = 0;
         size_t steps = (n - i) / 8;
@@ -154,7 +177,7 @@ static unsigned long long sum_bytes(const uint8_t *p, size_t n)
     return total;
 }
 
-/* one device: its share of the pairs, two batches in flight */
+/* one device: its share of the pairs; three buffer sets in flight over three streams */
 static void *worker_main(void *arg)
 {
     Worker *w = arg;
@@ -162,11 +185,12 @@ static void *worker_main(void *arg)
     const size_t n = (size_t)w->width * w->height;
     const int web_type = w->num_shifts <= 255 ? SM_WEB_U8 : SM_WEB_U16;
     const int web_bytes = web_type == SM_WEB_U8 ? 1 : 2;
-    sm_plan *plan[SLOTS] = {NULL};
-    void *stream[SLOTS] = {NULL};
+    sm_plan *plan = NULL;                 /* all kernels run on ONE stream, in order: one plan */
+    void *st_up = NULL, *st_run = NULL, *st_down = NULL;
+    void *ev_up[SLOTS] = {NULL}, *ev_ran[SLOTS] = {NULL}, *ev_down[SLOTS] = {NULL};
     uint8_t *d_in[SLOTS] = {NULL};
     void *h_web[SLOTS] = {NULL}, *d_web[SLOTS] = {NULL};
-    int in_flight[SLOTS] = {0}, first_index[SLOTS] = {0};
+    int in_flight[SLOTS] = {0}, first_index[SLOTS] = {0}, used[SLOTS] = {0};
 
     /* this device's pairs: j with j mod n_devices == rank, over all repeats */
     int mine = 0;
@@ -174,11 +198,16 @@ static void *worker_main(void *arg)
     const long total = (long)mine * w->repeat;
 
     /* allocation and set-up, before the clock starts (src/stereo.cu:296-308) */
+    if (sm_plan_create(dev, w->width, w->height, w->num_shifts, w->square_width, w->border,
+                       w->batch, &plan) ||
+        sm_plan_prepare_threshold(plan, w->threshold, NULL) ||
+        sm_stream_create(dev, &st_up) || sm_stream_create(dev, &st_run) || sm_stream_create(dev, &st_down)) {
+        snprintf(w->error, sizeof w->error, "%s", sm_last_error());
+        w->failed = 1;
+    }
     for (int s = 0; s < SLOTS && !w->failed; s++) {
-        if (sm_plan_create(dev, w->width, w->height, w->num_shifts, w->square_width, w->border,
-                           w->batch, &plan[s]) ||
-            sm_plan_prepare_threshold(plan[s], w->threshold, NULL) ||
-            sm_stream_create(dev, &stream[s]) ||
+        if (sm_event_create(dev, &ev_up[s]) || sm_event_create(dev, &ev_ran[s]) ||
+            sm_event_create(dev, &ev_down[s]) ||
             sm_host_alloc(n * web_bytes * w->batch, &h_web[s]) ||
             sm_malloc(dev, 2 * n * w->batch, (void **)&d_in[s]) ||
             sm_malloc(dev, n * web_bytes * w->batch, &d_web[s])) {
@@ -186,15 +215,17 @@ static void *worker_main(void *arg)
             w->failed = 1;
         }
     }
-    /* one pair through every slot before the clock starts: the first transfer and the first
+    /* one pair through every stream before the clock starts: the first transfer and the first
      * launch on a stream set up DMA queues and load code objects (tens of milliseconds) */
-    for (int s = 0; s < SLOTS && !w->failed && mine > 0; s++) {
+    if (!w->failed && mine > 0) {
         const int j = w->rank;
-        if (sm_memcpy_h2d_async(dev, d_in[s], w->pairs[j].px[0], n, stream[s]) ||
-            sm_memcpy_h2d_async(dev, d_in[s] + n, w->pairs[j].px[1], n, stream[s]) ||
-            sm_run_typed(plan[s], d_in[s], d_in[s] + n, w->threshold, 1, d_web[s], web_type, NULL, stream[s]) ||
-            sm_memcpy_d2h_async(dev, h_web[s], d_web[s], n * web_bytes, stream[s]) ||
-            sm_stream_sync(dev, stream[s])) {
+        if (sm_memcpy_h2d_async(dev, d_in[0], w->pairs[j].px[0], n, st_up) ||
+            sm_memcpy_h2d_async(dev, d_in[0] + n, w->pairs[j].px[1], n, st_up) ||
+            sm_stream_sync(dev, st_up) ||
+            sm_run_typed(plan, d_in[0], d_in[0] + n, w->threshold, 1, d_web[0], web_type, NULL, st_run) ||
+            sm_stream_sync(dev, st_run) ||
+            sm_memcpy_d2h_async(dev, h_web[0], d_web[0], n * web_bytes, st_down) ||
+            sm_stream_sync(dev, st_down)) {
             snprintf(w->error, sizeof w->error, "%s", sm_last_error());
             w->failed = 1;
         }
@@ -204,11 +235,11 @@ static void *worker_main(void *arg)
         goto out;
 
     long next = 0;            /* index into this device's sequence of pairs */
-    int s = 0;
-    while (next < total || in_flight[0] || in_flight[1]) {
-        /* collect what this slot carried two submissions ago */
+    int s = 0, busy = 0;
+    while (next < total || busy) {
+        /* collect what this slot carried SLOTS submissions ago */
         if (in_flight[s]) {
-            W_TRY(sm_stream_sync(dev, stream[s]));
+            W_TRY(sm_event_sync(dev, ev_down[s]));
             for (int k = 0; k < in_flight[s]; k++) {
                 const uint8_t *m8 = (const uint8_t *)h_web[s] + (size_t)k * n * web_bytes;
                 unsigned long long sum = 0;
@@ -226,34 +257,54 @@ static void *worker_main(void *arg)
                 w->done_pairs++;
             }
             in_flight[s] = 0;
+            busy--;
         }
         if (next < total) {
             /* upload the next batch straight from the pinned arena the images were decoded
-             * into: lefts then rights, as sm_run expects a batch (no staging copy on the host) */
+             * into: lefts then rights, as sm_run expects a batch (no staging copy on the host).
+             * The slot's input buffer is free once the kernels that last read it have run,
+             * its map buffer once the download that last read it has finished. */
             int b = 0;
             while (b < w->batch && next + b < total) b++;
+            if (used[s]) W_TRY(sm_stream_wait_event(dev, st_up, ev_ran[s]));
             for (int k = 0; k < b; k++) {
                 const int j = w->rank + (int)((next + k) % mine) * w->n_devices;
-                W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)k * n, w->pairs[j].px[0], n, stream[s]));
-                W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)(b + k) * n, w->pairs[j].px[1], n, stream[s]));
+                W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)k * n, w->pairs[j].px[0], n, st_up));
+                W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)(b + k) * n, w->pairs[j].px[1], n, st_up));
             }
-            W_TRY(sm_run_typed(plan[s], d_in[s], d_in[s] + (size_t)b * n, w->threshold, b, d_web[s],
-                               web_type, NULL, stream[s]));
-            W_TRY(sm_memcpy_d2h_async(dev, h_web[s], d_web[s], n * web_bytes * b, stream[s]));
+            W_TRY(sm_event_record(dev, ev_up[s], st_up));
+            W_TRY(sm_stream_wait_event(dev, st_run, ev_up[s]));
+            if (used[s]) W_TRY(sm_stream_wait_event(dev, st_run, ev_down[s]));
+            W_TRY(sm_run_typed(plan, d_in[s], d_in[s] + (size_t)b * n, w->threshold, b, d_web[s],
+                               web_type, NULL, st_run));
+            W_TRY(sm_event_record(dev, ev_ran[s], st_run));
+            W_TRY(sm_stream_wait_event(dev, st_down, ev_ran[s]));
+            W_TRY(sm_memcpy_d2h_async(dev, h_web[s], d_web[s], n * web_bytes * b, st_down));
+            W_TRY(sm_event_record(dev, ev_down[s], st_down));
+            used[s] = 1;
             in_flight[s] = b;
             first_index[s] = (int)next;
             next += b;
+            busy++;
         }
-        s ^= 1;
+        s = (s + 1) % SLOTS;
     }
 out:
+    if (st_up) sm_stream_sync(dev, st_up);
+    if (st_run) sm_stream_sync(dev, st_run);
+    if (st_down) sm_stream_sync(dev, st_down);
     for (int k = 0; k < SLOTS; k++) {
-        if (stream[k]) { sm_stream_sync(dev, stream[k]); sm_stream_destroy(dev, stream[k]); }
-        if (plan[k]) sm_plan_destroy(plan[k]);
+        if (ev_up[k]) sm_event_destroy(dev, ev_up[k]);
+        if (ev_ran[k]) sm_event_destroy(dev, ev_ran[k]);
+        if (ev_down[k]) sm_event_destroy(dev, ev_down[k]);
         if (h_web[k]) sm_host_free(h_web[k]);
         if (d_in[k]) sm_free(dev, d_in[k]);
         if (d_web[k]) sm_free(dev, d_web[k]);
     }
+    if (st_up) sm_stream_destroy(dev, st_up);
+    if (st_run) sm_stream_destroy(dev, st_run);
+    if (st_down) sm_stream_destroy(dev, st_down);
+    if (plan) sm_plan_destroy(plan);
     return NULL;
 }
 
