@@ -524,6 +524,76 @@ def test_pipelined_runs_and_kernel_timing(hip):
     plan.close()
 
 
+def test_c_abi_three_streams_chained_with_events(hip):
+    """uploads, kernels and downloads on a stream each (the pattern of stereopar_batch.c and
+    tools/e2e_bench.py): 12 DIFFERENT 1080p pairs through 3 buffer sets; sm_event_record /
+    sm_stream_wait_event / sm_event_sync are all that orders them.  Every map must be the
+    map of ITS pair -- a missing wait shows up as a neighbour's result or a torn one."""
+    import ctypes as C
+    lib, check = hip.capi.lib, hip.capi.check
+    w, h, d, sw = 1920, 1080, 64, 7
+    n, slots, npairs = w * h, 3, 12
+    vp = C.c_void_p
+    pairs = [make_pair(w, h, d, seed=900 + j) for j in range(4)]
+
+    def make(fn, *a):
+        p = vp()
+        check(fn(*a, C.byref(p)))
+        return p
+    st_up, st_run, st_down = (make(lib.sm_stream_create, 0) for _ in range(3))
+    plan = make(lib.sm_plan_create, 0, w, h, d, sw, 0, 1)
+    S = [dict(hl=make(lib.sm_host_alloc, n), hr=make(lib.sm_host_alloc, n), hw=make(lib.sm_host_alloc, n),
+              dl=make(lib.sm_malloc, 0, n), dr=make(lib.sm_malloc, 0, n), dw=make(lib.sm_malloc, 0, n),
+              up=make(lib.sm_event_create, 0), ran=make(lib.sm_event_create, 0),
+              down=make(lib.sm_event_create, 0), pair=None) for _ in range(slots)]
+    want = {}
+    got = []
+
+    def collect(s):
+        check(lib.sm_event_sync(0, s["down"]))
+        got.append((s["pair"], np.ctypeslib.as_array(C.cast(s["hw"], C.POINTER(C.c_uint8)), (h, w)).copy()))
+
+    for k in range(npairs):
+        s = S[k % slots]
+        if s["pair"] is not None:
+            collect(s)
+            check(lib.sm_stream_wait_event(0, st_up, s["ran"]))
+        j = k % len(pairs)
+        C.memmove(s["hl"], pairs[j][0].ctypes.data, n)      # the slot's host buffers are free: collected
+        C.memmove(s["hr"], pairs[j][1].ctypes.data, n)
+        check(lib.sm_memcpy_h2d_async(0, s["dl"], s["hl"], n, st_up))
+        check(lib.sm_memcpy_h2d_async(0, s["dr"], s["hr"], n, st_up))
+        check(lib.sm_event_record(0, s["up"], st_up))
+        check(lib.sm_stream_wait_event(0, st_run, s["up"]))
+        if s["pair"] is not None:
+            check(lib.sm_stream_wait_event(0, st_run, s["down"]))
+        check(lib.sm_run_typed(plan, s["dl"], s["dr"], 0.15, 1, s["dw"], hip.capi.SM_WEB_U8, None, st_run))
+        check(lib.sm_event_record(0, s["ran"], st_run))
+        check(lib.sm_stream_wait_event(0, st_down, s["ran"]))
+        check(lib.sm_memcpy_d2h_async(0, s["hw"], s["dw"], n, st_down))
+        check(lib.sm_event_record(0, s["down"], st_down))
+        s["pair"] = j
+    for k in range(npairs, npairs + slots):
+        collect(S[k % slots])
+    assert len(got) == npairs
+    for j, web in got:
+        if j not in want:
+            want[j] = oracle.pipeline(*pairs[j], 0.15, d, sw, step3=False)["web-1"].astype(np.uint8)
+        assert np.array_equal(web, want[j]), j
+    with pytest.raises(hip.capi.StereoHipError, match="sm_event_record"):
+        check(lib.sm_event_record(0, None, st_up))
+    lib.sm_plan_destroy(plan)
+    for s in S:
+        for k in ("dl", "dr", "dw"):
+            check(lib.sm_free(0, s[k]))
+        for k in ("hl", "hr", "hw"):
+            check(lib.sm_host_free(s[k]))
+        for k in ("up", "ran", "down"):
+            check(lib.sm_event_destroy(0, s[k]))
+    for st in (st_up, st_run, st_down):
+        check(lib.sm_stream_destroy(0, st))
+
+
 def test_c_abi_alone_with_pinned_async_transfers(hip):
     """the boundary without torch: device memory, pinned host memory, a stream and
     async copies all come from the C ABI (what a C caller would do)"""
