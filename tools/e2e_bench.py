@@ -82,8 +82,17 @@ def measure_one(cfg: str, device: int, web_type: int, npairs: int = 24, slots: i
         check(lib.sm_event_record(device, s["down"], st_down))
         s["used"] = True
 
-    for s in S:                      # warm-up
-        submit(s)
+    # warm-up: every slot at least twice, and at least 40 ms of traffic -- a link that has been
+    # idle (bench.py calls this after a timed region without transfers) takes ~20 ms to leave its
+    # low-power state, during which a 33 MB download runs at half speed
+    t_warm = time.perf_counter()
+    rounds = 0
+    while rounds < 2 or time.perf_counter() - t_warm < 0.040:
+        for s in S:
+            if s["used"]:
+                check(lib.sm_event_sync(device, s["down"]))
+            submit(s)
+        rounds += 1
     check(lib.sm_stream_sync(device, st_down))
     t0 = time.perf_counter()
     for k in range(npairs):
