@@ -1139,7 +1139,14 @@ extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int
     // the launches, and record the buffer-release event only when someone can wait on it
     const bool timed = plan->timing_n < plan->timing_cap &&
                        plan->timing_seen++ % plan->timing_every == 0;
-    if (timed) SM_HIP(hipEventRecord(plan->t_begin[plan->timing_n], (hipStream_t)stream));
+    // The bit-sliced kernel's launcher attaches the two events to the dispatch packet itself
+    // (the completion signal's own start / end time stamps): no extra packets on the stream.
+    // Separate event records cost ~4 us each there, 6 % of a 4K step when every second launch
+    // is timed (bench.py at --steps 20).  Other kernels keep the bracketing records.
+    const bool attach = timed && plan->kernel == SM_KERNEL_BS && !via_tmp && !getenv("SM_TIMING_RECORDS");
+    if (timed && !attach) SM_HIP(hipEventRecord(plan->t_begin[plan->timing_n], (hipStream_t)stream));
+    plan->launch_ev_begin = attach ? plan->t_begin[plan->timing_n] : nullptr;
+    plan->launch_ev_end = attach ? plan->t_end[plan->timing_n] : nullptr;
     {
         // int4 stores need 16-byte aligned maps; otherwise this launch stores scalars
         // (kernel arguments are copied at launch time)
@@ -1158,7 +1165,9 @@ extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int
             SM_LAUNCH_CHECK("k_narrow_web");
         }
     }
-    if (timed) SM_HIP(hipEventRecord(plan->t_end[plan->timing_n++], (hipStream_t)stream));
+    if (timed && !attach) SM_HIP(hipEventRecord(plan->t_end[plan->timing_n], (hipStream_t)stream));
+    if (timed) plan->timing_n++;
+    plan->launch_ev_begin = plan->launch_ev_end = nullptr;
     if (plan->pipelined) {
         // the next-but-one sm_run must not overwrite this buffer before the launch has read it
         SM_HIP(hipEventRecord(plan->ev_free[plan->cur], (hipStream_t)stream));

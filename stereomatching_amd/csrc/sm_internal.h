@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -81,6 +82,9 @@ struct sm_plan {
     int timing_cap, timing_n, timing_every, timing_seen;
     hipEvent_t *t_begin, *t_end;
     i32 *d_web_tmp;      // int32 map for narrow results of kernels without a narrow store path
+    // the events of a timed launch, for a launcher that can attach them to the dispatch itself
+    // (sm_bs_launch: hipExtLaunchKernel); it clears them when it has done so
+    hipEvent_t launch_ev_begin, launch_ev_end;
     i32 *d_flags;        // [0] = zero-interval flag, [1] = has-zero scratch,
                          // [2] = edge table is not of threshold form
     i32 *h_flags;        // pinned host copy of d_flags (k_publish_flags)

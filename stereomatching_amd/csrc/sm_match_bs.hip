@@ -90,8 +90,12 @@ int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t 
     const void *fn = sm_bs_kernel_ptr(g.n, g.ds, g.nl * g.ds == g.D, plan->border == SM_GHOST, g.cap2 != 0, g.duo != 0);
     if (!fn) return sm_fail(SM_ERR_ARG, "bit-sliced kernel not built for n = %d, %d shifts/lane", g.n, g.ds);
     void *args[] = {(void *)&plan->d_ext, (void *)&d_web, (void *)&d_best, (void *)&g};
-    hipError_t e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(g.threads), args,
-                                   g.lds_bytes, st);
+    hipError_t e;
+    if (plan->launch_ev_begin)      // a timed launch: the events ride on the dispatch (sm_match_wta_typed)
+        e = hipExtLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(g.threads), args, g.lds_bytes, st,
+                               plan->launch_ev_begin, plan->launch_ev_end, 0);
+    else
+        e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(g.threads), args, g.lds_bytes, st);
     if (e != hipSuccess)
         return sm_fail(SM_ERR_HIP, "launch of k_match_bs failed: %s", hipGetErrorString(e));
     return SM_OK;
