@@ -196,6 +196,16 @@ def main():
     dryrun = os.environ.get("SM_BENCH_DRYRUN") == "1"
     rehearsal = dryrun or os.environ.get("SM_BENCH_REHEARSAL") == "1"
 
+    # stdout carries ONE JSON line and nothing else: libraries write to file descriptor 1 behind
+    # Python's back (gloo announces its connections there, a runtime may warn there), so from here
+    # on fd 1 is stderr and the line goes to a duplicate of the real stdout at the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str) -> None:
+        os.write(real_stdout, (line + "\n").encode())
+
     import torch
     from stereomatching_amd import shard
     from stereomatching_amd.synth import CONFIGS, make_pair
@@ -234,13 +244,12 @@ def main():
         shard.barrier()
         elapsed = shard.max_over_ranks(time.perf_counter() - t0, "cpu")
         if rank == 0:
-            print(json.dumps({"metric": "Mpixel-disparities/s", "value": 0.0,
-                              "unit": "Mpixel-disparities/s", "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                              "dry_run": True, "data": "none: SM_BENCH_DRYRUN plumbing rehearsal, no GPU work",
-                              "config": {"workload": f"{args.config} x {pairs} pair(s)/rank (not run)"}}),
-                  flush=True)
+            emit(json.dumps({"metric": "Mpixel-disparities/s", "value": 0.0,
+                             "unit": "Mpixel-disparities/s", "n_gpus": world, "steps": args.steps,
+                             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                             "dry_run": True, "data": "none: SM_BENCH_DRYRUN plumbing rehearsal, no GPU work",
+                             "config": {"workload": f"{args.config} x {pairs} pair(s)/rank (not run)"}}))
         shard.finalize()
         return
 
@@ -410,7 +419,7 @@ def main():
         out["e2e"] = e2e_bench.measure(args.config, local_rank)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, d, sw, mode, args.cpu_rows, args.threshold)
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     shard.finalize()
 
 
