@@ -110,6 +110,8 @@ def test_bench_starts_its_own_ranks():
                       SM_BENCH_DRYRUN="1")
     assert p.returncode == 0, p.stderr[-2000:]
     assert len(lines) == 1
+    # and NOTHING else on stdout: gloo announces its connections on file descriptor 1
+    assert len(p.stdout.strip().splitlines()) == 1, p.stdout[:500]
     out = lines[0]
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
     assert out["dry_run"] is True and out["value"] == 0.0       # can never pass for a measurement
