@@ -50,6 +50,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 # instruction issues over 2 cycles -> wave-instructions per second, whole chip
 VALU_PEAK_GIPS = 256 * 4 * 2.4 / 2.0 * 1.0      # = 1228.8 G wave-instr/s
 WARMUP_FLOOR_S = 0.025          # minimum duration of the warm-up (clock ramp), see main()
+WARMUP_BURST = 16         # untimed steps right in front of the timed region (see main)
 A_CV_BYTES = 10.0               # per pixel-disparity
 A_MIN_BYTES = 6.0               # per pixel          
 
@@ -294,6 +295,12 @@ def main():
     # left its idle clocks (the same kernel measures ~10 % slower in the first millisecond
     # than in steady state).  The warm-up therefore also lasts at least WARMUP_FLOOR_S;
     # the number of steps it took is reported as warmup_steps_run.
+    # HIP events around the dominant kernel, recorded by the library on the stream the kernel
+    # is launched on, inside the timed region itself.  The events are CREATED here, before the
+    # warm-up (which uses them too); re-arming them in front of the timed region is free.
+    every = timing_stride(args.steps)
+    n_samples = (args.steps + every - 1) // every
+    plan.time_kernels(n_samples, every)
     warm_t0 = time.perf_counter()
     warm_steps = 0
     while warm_steps < args.warmup or time.perf_counter() - warm_t0 < WARMUP_FLOOR_S:
@@ -305,11 +312,15 @@ def main():
     # communicator start-up (RCCL) belongs to the warm-up, not to the timed region
     shard.barrier()
     shard.max_over_ranks(0.0, red_dev)
-    # HIP events around the dominant kernel, recorded by the library on the stream
-    # the kernel is launched on, inside the timed region itself
-    every = timing_stride(args.steps)
-    n_samples = (args.steps + every - 1) // every
-    plan.time_kernels(n_samples, every)
+    # The host work since the warm-up (the communicator's first collectives take milliseconds)
+    # left the chip idle, and it drops its clocks within a fraction of a millisecond: a last
+    # burst of untimed steps keeps it busy until the barrier + synchronize that open the timed
+    # region (a timed region of 20 steps is only 2 ms long; without the burst its first
+    # launches ran ~10 % slower and the line read 0.099 ms per step where 200 steps read 0.0955)
+    for _ in range(WARMUP_BURST):
+        step()
+    warm_steps += WARMUP_BURST
+    plan.time_kernels(n_samples, every)        # re-arm: same capacity, no allocation
 
     shard.barrier()
     torch.cuda.synchronize(dev)
@@ -394,7 +405,8 @@ def main():
         "warmup": args.warmup,
         "warmup_steps_run": warm_steps,
         "warmup_note": f"{args.warmup} steps asked; untimed warm-up continued to {WARMUP_FLOOR_S * 1e3:.0f} ms "
-                       "so that the timed steps run at steady clocks",
+                       f"and ends with {WARMUP_BURST} steps right in front of the timed region, so that "
+                       "the timed steps run at steady clocks",
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
