@@ -427,8 +427,19 @@ def main():
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
     if world == 1 and not args.no_e2e and not rehearsal:
-        from tools import e2e_bench
-        out["e2e"] = e2e_bench.measure(args.config, local_rank)
+        # the C ABI alone, in a process of its own (a child, started -- not exec'ed -- from here):
+        # what a C host sees.  Inside this process, behind torch and the timed loop, the same
+        # code measures the 33 MB downloads ~13 % slower (0.76 vs 0.66 ms per pair) for a reason
+        # that was not found; should the child fail, that in-process figure is reported and marked.
+        try:
+            r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / "tools" / "e2e_bench.py"),
+                                args.config, "24", str(local_rank)], capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            out["e2e"] = dict(json.loads(line), process="child process of bench.py (C ABI only, no torch)")
+        except Exception as exc:       # noqa: BLE001 -- any failure: measure here instead
+            from tools import e2e_bench
+            out["e2e"] = dict(e2e_bench.measure(args.config, local_rank),
+                              process=f"in-process (child failed: {type(exc).__name__})")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, d, sw, mode, args.cpu_rows, args.threshold)
     emit(json.dumps(out))

@@ -6,7 +6,7 @@ same time, both directions of the link busy), chained with events over per-slot 
 measured with resident inputs); bench.py (N = 1) reports it as the extra object `e2e` and
 DESIGN.md quotes it next to the resident number.
 
-    python tools/e2e_bench.py [C3] [pairs=24] [slots=3]
+    python tools/e2e_bench.py [C3] [pairs=24] [device=0]
 
 Measured for the reference's int32 web map (sm_run) and for the narrow map
 (sm_run_typed: uint8 when the shifts fit, else uint16), which moves 4x / 2x fewer
@@ -82,12 +82,12 @@ def measure_one(cfg: str, device: int, web_type: int, npairs: int = 24, slots: i
         check(lib.sm_event_record(device, s["down"], st_down))
         s["used"] = True
 
-    # warm-up: every slot at least twice, and at least 40 ms of traffic -- a link that has been
-    # idle (bench.py calls this after a timed region without transfers) takes ~20 ms to leave its
+    # warm-up: every slot at least twice, and at least 150 ms of traffic -- a link that has been
+    # idle (bench.py calls this after a timed region without transfers) takes tens of milliseconds to leave its
     # low-power state, during which a 33 MB download runs at half speed
     t_warm = time.perf_counter()
     rounds = 0
-    while rounds < 2 or time.perf_counter() - t_warm < 0.040:
+    while rounds < 2 or time.perf_counter() - t_warm < 0.150:
         for s in S:
             if s["used"]:
                 check(lib.sm_event_sync(device, s["down"]))
@@ -145,4 +145,5 @@ if __name__ == "__main__":
     import json
     cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
     npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-    print(json.dumps(measure(cfg, 0, npairs)))
+    device = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    print(json.dumps(measure(cfg, device, npairs)))
