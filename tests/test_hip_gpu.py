@@ -434,6 +434,26 @@ def test_two_wave_workgroups_match_oracle(hip, env, mode, sw, d, h, tile_h):
     assert np.array_equal(best[0], obest), desc
 
 
+@pytest.mark.parametrize("cfg,pairs", [("C3", 1), ("C4", 8), ("C5", 1)])
+def test_match_launch_is_deterministic(hip, cfg, pairs):
+    """300 launches on the same edges give the same maps every time, bit for bit: the waves of
+    a two-wave workgroup swap sums through LDS between two barriers and share a SIMD with waves
+    of other workgroups at alternating priorities -- a missing barrier or a lost wait would show
+    up as a map that differs in SOME launch (the full-image parity tests look at one)."""
+    w, h, d, sw, mode = CONFIGS[cfg]
+    ls, rs = zip(*[make_pair(w, h, d, seed=70 + j) for j in range(pairs)])
+    plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
+    plan.find_all_edges(dev(np.stack(ls)), dev(np.stack(rs)), 0.15, want_edges=False)
+    web, best = plan.match_wta(pairs, want_best=True)
+    ref_web, ref_best = web.clone(), best.clone()
+    bad = torch.zeros((), dtype=torch.int32, device=web.device)       # launches that differed
+    for i in range(300):
+        web, best = plan.match_wta(pairs, want_best=True, web=web, best=best)
+        bad += ((web != ref_web).any() | (best != ref_best).any()).to(torch.int32)
+    assert int(bad.item()) == 0, (int(bad.item()), plan.describe())
+    plan.close()
+
+
 BUILT_BS = [(n, 16) for n in (3, 5, 7, 9, 11)] + [(n, 8) for n in range(3, 22, 2)]
 
 
