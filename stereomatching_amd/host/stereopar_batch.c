@@ -41,6 +41,7 @@
 #include "stereo_hip.h"
 
 #include <pthread.h>
+#include <semaphore.h>
 #ifdef __SSE2__
 #include <emmintrin.h>
 #endif
@@ -74,8 +75,16 @@ typedef struct {
     /* result */
     unsigned long long checksum;
     int done_pairs;
-    int failed;
+    volatile int failed;      /* set by either of the device's two host threads, read by both */
     char error[512];
+    /* the device's two host threads: the submitter (worker_main) queues batches into SLOTS
+     * buffer sets; the collector (collector_main) waits for each download, sums and writes the
+     * maps and hands the set back -- reading 2 MB per map takes the host longer than the GPU
+     * and the link need for it, so it must not sit between two submissions */
+    sem_t slot_free, slot_filled;
+    int in_flight[SLOTS], first_index[SLOTS];     /* pairs in the set (0: the end), first pair's index */
+    void *ev_down[SLOTS], *h_web[SLOTS];
+    int mine, web_bytes;
 } Worker;
 
 static double get_time(void)
@@ -177,6 +186,41 @@ static unsigned long long sum_bytes(const uint8_t *p, size_t n)
     return total;
 }
 
+/* the collector of one device: batches come back in the order they were submitted */
+static void *collector_main(void *arg)
+{
+    Worker *w = arg;
+    const size_t n = (size_t)w->width * w->height;
+    for (int s = 0;; s = (s + 1) % SLOTS) {
+        sem_wait(&w->slot_filled);
+        const int b = w->in_flight[s];
+        if (b == 0)
+            break;                          /* the submitter's end marker */
+        if (!w->failed && sm_event_sync(w->device, w->ev_down[s]) != SM_OK) {
+            snprintf(w->error, sizeof w->error, "%s", sm_last_error());
+            w->failed = 1;
+        }
+        for (int k = 0; k < b && !w->failed; k++) {
+            const uint8_t *m8 = (const uint8_t *)w->h_web[s] + (size_t)k * n * w->web_bytes;
+            unsigned long long sum = 0;
+            if (w->web_bytes == 1) {
+                sum = sum_bytes(m8, n);
+            } else {            /* little-endian uint16: low bytes + 256 * high bytes */
+                const uint16_t *m16 = (const uint16_t *)m8;
+                for (size_t i = 0; i < n; i++) sum += m16[i];
+            }
+            w->checksum += sum;
+            const long seq = w->first_index[s] + k;                         /* in this device's sequence */
+            const int j = w->rank + (int)(seq % w->mine) * w->n_devices;    /* global pair index */
+            if (w->out_dir && seq < w->mine)
+                write_pgm(w->out_dir, j, m8, w->web_bytes, w->width, w->height, w->num_shifts);
+            w->done_pairs++;
+        }
+        sem_post(&w->slot_free);
+    }
+    return NULL;
+}
+
 /* one device: its share of the pairs; three buffer sets in flight over three streams */
 static void *worker_main(void *arg)
 {
@@ -187,15 +231,21 @@ static void *worker_main(void *arg)
     const int web_bytes = web_type == SM_WEB_U8 ? 1 : 2;
     sm_plan *plan = NULL;                 /* all kernels run on ONE stream, in order: one plan */
     void *st_up = NULL, *st_run = NULL, *st_down = NULL;
-    void *ev_up[SLOTS] = {NULL}, *ev_ran[SLOTS] = {NULL}, *ev_down[SLOTS] = {NULL};
+    void *ev_up[SLOTS] = {NULL}, *ev_ran[SLOTS] = {NULL};
     uint8_t *d_in[SLOTS] = {NULL};
-    void *h_web[SLOTS] = {NULL}, *d_web[SLOTS] = {NULL};
-    int in_flight[SLOTS] = {0}, first_index[SLOTS] = {0}, used[SLOTS] = {0};
+    void *d_web[SLOTS] = {NULL};
+    int used[SLOTS] = {0};
+    pthread_t collector;
+    int collector_started = 0;
 
     /* this device's pairs: j with j mod n_devices == rank, over all repeats */
     int mine = 0;
     for (int j = w->rank; j < w->n_pairs; j += w->n_devices) mine++;
     const long total = (long)mine * w->repeat;
+    w->mine = mine;
+    w->web_bytes = web_bytes;
+    sem_init(&w->slot_free, 0, SLOTS);
+    sem_init(&w->slot_filled, 0, 0);
 
     /* allocation and set-up, before the clock starts (src/stereo.cu:296-308) */
     if (sm_plan_create(dev, w->width, w->height, w->num_shifts, w->square_width, w->border,
@@ -207,8 +257,8 @@ static void *worker_main(void *arg)
     }
     for (int s = 0; s < SLOTS && !w->failed; s++) {
         if (sm_event_create(dev, &ev_up[s]) || sm_event_create(dev, &ev_ran[s]) ||
-            sm_event_create(dev, &ev_down[s]) ||
-            sm_host_alloc(n * web_bytes * w->batch, &h_web[s]) ||
+            sm_event_create(dev, &w->ev_down[s]) ||
+            sm_host_alloc(n * web_bytes * w->batch, &w->h_web[s]) ||
             sm_malloc(dev, 2 * n * w->batch, (void **)&d_in[s]) ||
             sm_malloc(dev, n * web_bytes * w->batch, &d_web[s])) {
             snprintf(w->error, sizeof w->error, "%s", sm_last_error());
@@ -224,80 +274,76 @@ static void *worker_main(void *arg)
             sm_stream_sync(dev, st_up) ||
             sm_run_typed(plan, d_in[0], d_in[0] + n, w->threshold, 1, d_web[0], web_type, NULL, st_run) ||
             sm_stream_sync(dev, st_run) ||
-            sm_memcpy_d2h_async(dev, h_web[0], d_web[0], n * web_bytes, st_down) ||
+            sm_memcpy_d2h_async(dev, w->h_web[0], d_web[0], n * web_bytes, st_down) ||
             sm_stream_sync(dev, st_down)) {
             snprintf(w->error, sizeof w->error, "%s", sm_last_error());
             w->failed = 1;
         }
+    }
+    if (!w->failed && pthread_create(&collector, NULL, collector_main, w) == 0)
+        collector_started = 1;
+    else if (!w->failed) {
+        snprintf(w->error, sizeof w->error, "error: cannot start the collector thread");
+        w->failed = 1;
     }
     pthread_barrier_wait(w->start);       /* main() takes t1 here */
     if (w->failed)
         goto out;
 
     long next = 0;            /* index into this device's sequence of pairs */
-    int s = 0, busy = 0;
-    while (next < total || busy) {
-        /* collect what this slot carried SLOTS submissions ago */
-        if (in_flight[s]) {
-            W_TRY(sm_event_sync(dev, ev_down[s]));
-            for (int k = 0; k < in_flight[s]; k++) {
-                const uint8_t *m8 = (const uint8_t *)h_web[s] + (size_t)k * n * web_bytes;
-                unsigned long long sum = 0;
-                if (web_bytes == 1) {
-                    sum = sum_bytes(m8, n);
-                } else {            /* little-endian uint16: low bytes + 256 * high bytes */
-                    const uint16_t *m16 = (const uint16_t *)m8;
-                    for (size_t i = 0; i < n; i++) sum += m16[i];
-                }
-                w->checksum += sum;
-                const long seq = first_index[s] + k;                 /* in this device's sequence */
-                const int j = w->rank + (int)(seq % mine) * w->n_devices;   /* global pair index */
-                if (w->out_dir && seq < mine)
-                    write_pgm(w->out_dir, j, m8, web_bytes, w->width, w->height, w->num_shifts);
-                w->done_pairs++;
-            }
-            in_flight[s] = 0;
-            busy--;
+    for (int s = 0; next < total && !w->failed; s = (s + 1) % SLOTS) {
+        sem_wait(&w->slot_free);          /* the collector is done with this set's previous maps */
+        /* upload the next batch straight from the pinned arena the images were decoded
+         * into: lefts then rights, as sm_run expects a batch (no staging copy on the host).
+         * The set's input buffer is free once the kernels that last read it have run,
+         * its map buffer once the download that last read it has finished. */
+        int b = 0;
+        while (b < w->batch && next + b < total) b++;
+        if (used[s]) W_TRY(sm_stream_wait_event(dev, st_up, ev_ran[s]));
+        for (int k = 0; k < b; k++) {
+            const int j = w->rank + (int)((next + k) % mine) * w->n_devices;
+            W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)k * n, w->pairs[j].px[0], n, st_up));
+            W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)(b + k) * n, w->pairs[j].px[1], n, st_up));
         }
-        if (next < total) {
-            /* upload the next batch straight from the pinned arena the images were decoded
-             * into: lefts then rights, as sm_run expects a batch (no staging copy on the host).
-             * The slot's input buffer is free once the kernels that last read it have run,
-             * its map buffer once the download that last read it has finished. */
-            int b = 0;
-            while (b < w->batch && next + b < total) b++;
-            if (used[s]) W_TRY(sm_stream_wait_event(dev, st_up, ev_ran[s]));
-            for (int k = 0; k < b; k++) {
-                const int j = w->rank + (int)((next + k) % mine) * w->n_devices;
-                W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)k * n, w->pairs[j].px[0], n, st_up));
-                W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)(b + k) * n, w->pairs[j].px[1], n, st_up));
-            }
-            W_TRY(sm_event_record(dev, ev_up[s], st_up));
-            W_TRY(sm_stream_wait_event(dev, st_run, ev_up[s]));
-            if (used[s]) W_TRY(sm_stream_wait_event(dev, st_run, ev_down[s]));
-            W_TRY(sm_run_typed(plan, d_in[s], d_in[s] + (size_t)b * n, w->threshold, b, d_web[s],
-                               web_type, NULL, st_run));
-            W_TRY(sm_event_record(dev, ev_ran[s], st_run));
-            W_TRY(sm_stream_wait_event(dev, st_down, ev_ran[s]));
-            W_TRY(sm_memcpy_d2h_async(dev, h_web[s], d_web[s], n * web_bytes * b, st_down));
-            W_TRY(sm_event_record(dev, ev_down[s], st_down));
-            used[s] = 1;
-            in_flight[s] = b;
-            first_index[s] = (int)next;
-            next += b;
-            busy++;
-        }
-        s = (s + 1) % SLOTS;
+        W_TRY(sm_event_record(dev, ev_up[s], st_up));
+        W_TRY(sm_stream_wait_event(dev, st_run, ev_up[s]));
+        if (used[s]) W_TRY(sm_stream_wait_event(dev, st_run, w->ev_down[s]));
+        W_TRY(sm_run_typed(plan, d_in[s], d_in[s] + (size_t)b * n, w->threshold, b, d_web[s],
+                           web_type, NULL, st_run));
+        W_TRY(sm_event_record(dev, ev_ran[s], st_run));
+        W_TRY(sm_stream_wait_event(dev, st_down, ev_ran[s]));
+        W_TRY(sm_memcpy_d2h_async(dev, w->h_web[s], d_web[s], n * web_bytes * b, st_down));
+        W_TRY(sm_event_record(dev, w->ev_down[s], st_down));
+        used[s] = 1;
+        w->first_index[s] = (int)next;
+        w->in_flight[s] = b;
+        next += b;
+        sem_post(&w->slot_filled);
     }
 out:
+    if (collector_started) {
+        /* end marker in the next set the collector will look at: it takes them in submission
+         * order, so that is the one after the last batch (wait until it is free) */
+        if (!w->failed) {
+            long batches = (total + w->batch - 1) / w->batch;
+            sem_wait(&w->slot_free);
+            w->in_flight[batches % SLOTS] = 0;
+            sem_post(&w->slot_filled);
+        } else {
+            /* an error: the collector skips the work of whatever is queued; mark every set */
+            for (int k = 0; k < SLOTS; k++) w->in_flight[k] = 0;
+            sem_post(&w->slot_filled);
+        }
+        pthread_join(collector, NULL);
+    }
     if (st_up) sm_stream_sync(dev, st_up);
     if (st_run) sm_stream_sync(dev, st_run);
     if (st_down) sm_stream_sync(dev, st_down);
     for (int k = 0; k < SLOTS; k++) {
         if (ev_up[k]) sm_event_destroy(dev, ev_up[k]);
         if (ev_ran[k]) sm_event_destroy(dev, ev_ran[k]);
-        if (ev_down[k]) sm_event_destroy(dev, ev_down[k]);
-        if (h_web[k]) sm_host_free(h_web[k]);
+        if (w->ev_down[k]) sm_event_destroy(dev, w->ev_down[k]);
+        if (w->h_web[k]) sm_host_free(w->h_web[k]);
         if (d_in[k]) sm_free(dev, d_in[k]);
         if (d_web[k]) sm_free(dev, d_web[k]);
     }
@@ -305,6 +351,8 @@ out:
     if (st_run) sm_stream_destroy(dev, st_run);
     if (st_down) sm_stream_destroy(dev, st_down);
     if (plan) sm_plan_destroy(plan);
+    sem_destroy(&w->slot_free);
+    sem_destroy(&w->slot_filled);
     return NULL;
 }
 
