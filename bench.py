@@ -197,6 +197,23 @@ def main():
     dryrun = os.environ.get("SM_BENCH_DRYRUN") == "1"
     rehearsal = dryrun or os.environ.get("SM_BENCH_REHEARSAL") == "1"
 
+    # The extra `e2e` object (N = 1): the PCIe-inclusive rate through the C ABI alone, measured
+    # by a process of its own -- what a C host sees -- and BEFORE this process touches the GPU,
+    # so that no process is started from one that has initialised it.  (Inside this process,
+    # behind torch and the timed loop, the same code measured the 33 MB downloads ~13 % slower,
+    # 0.76 vs 0.66 ms per pair, for a reason that was not found.)  Never part of `value`.
+    e2e = None
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_e2e and not rehearsal:
+        try:
+            r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / "tools" / "e2e_bench.py"),
+                                args.config, "24", os.environ.get("LOCAL_RANK", "0")],
+                               capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            e2e = dict(json.loads(line), process="a process of its own, run before the timed region "
+                                                 "(C ABI only, no torch)")
+        except Exception as exc:       # noqa: BLE001 -- reported, never fatal: it is an extra
+            e2e = {"error": f"{type(exc).__name__}: e2e measurement failed"}
+
     # stdout carries ONE JSON line and nothing else: libraries write to file descriptor 1 behind
     # Python's back (gloo announces its connections there, a runtime may warn there), so from here
     # on fd 1 is stderr and the line goes to a duplicate of the real stdout at the very end
@@ -426,20 +443,8 @@ def main():
         out["rehearsal"] = "SM_BENCH_REHEARSAL: all ranks on device 0 over gloo"
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
-    if world == 1 and not args.no_e2e and not rehearsal:
-        # the C ABI alone, in a process of its own (a child, started -- not exec'ed -- from here):
-        # what a C host sees.  Inside this process, behind torch and the timed loop, the same
-        # code measures the 33 MB downloads ~13 % slower (0.76 vs 0.66 ms per pair) for a reason
-        # that was not found; should the child fail, that in-process figure is reported and marked.
-        try:
-            r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / "tools" / "e2e_bench.py"),
-                                args.config, "24", str(local_rank)], capture_output=True, text=True, timeout=300)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-            out["e2e"] = dict(json.loads(line), process="child process of bench.py (C ABI only, no torch)")
-        except Exception as exc:       # noqa: BLE001 -- any failure: measure here instead
-            from tools import e2e_bench
-            out["e2e"] = dict(e2e_bench.measure(args.config, local_rank),
-                              process=f"in-process (child failed: {type(exc).__name__})")
+    if e2e is not None:
+        out["e2e"] = e2e
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, d, sw, mode, args.cpu_rows, args.threshold)
     emit(json.dumps(out))
