@@ -26,7 +26,7 @@ CFLAGS := -std=gnu11 -Wall -Wextra -pedantic -Wno-unused-parameter -Iinclude -Io
 
 HOSTDIR := stereomatching_amd/host
 CSRC    := stereomatching_amd/csrc
-KERNELS := sm_match_bs_ds8 sm_match_bs sm_match_bs_duo8 sm_match_bs_duo sm_api sm_match sm_cost
+KERNELS := sm_match_bs_ds8 sm_match_bs sm_match_bs_duo8 sm_match_bs_duo sm_api sm_match sm_cost sm_cost_qs
 DEVOBJ  := $(addprefix stereomatching_amd/obj/product/,$(addsuffix .o,$(KERNELS)))
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-result -Iinclude -I$(CSRC)
 DEVLIB  := stereomatching_amd/libstereo_hip.so
@@ -42,7 +42,7 @@ $(O):
 	mkdir -p $@
 
 # (the bit-sliced kernel's builds are four translation units: `make -j4` compiles them side by side)
-stereomatching_amd/obj/product/%.o: $(CSRC)/%.hip $(CSRC)/sm_internal.h $(CSRC)/sm_match_bs_kernel.h include/stereo_hip.h
+stereomatching_amd/obj/product/%.o: $(CSRC)/%.hip $(CSRC)/sm_internal.h $(CSRC)/sm_match_bs_kernel.h $(CSRC)/sm_cost.h include/stereo_hip.h
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(DEVLIB): $(DEVOBJ)

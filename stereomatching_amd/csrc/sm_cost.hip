@@ -21,6 +21,7 @@
 // the two gray images into LDS (border rule applied while staging).
 
 #include "sm_internal.h"
+#include "sm_cost.h"
 
 #define SMC_DS 8        // shifts per lane
 #define SMC_PX 4        // pixels per lane
@@ -49,6 +50,7 @@ struct CostGeom {
     int nsr, tiles_x, tiles_y;
     int pad;                 // bytes left of the tile in a staged row (multiple of 4, >= half)
     int vec_ok;
+    int xlim;                // only pixel groups left of this column are computed (the whole image: w)
 };
 
 template <int NWD, bool SSD, bool GHOST>
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void k_cost_wta(const u8 *__restrict__ left,
     const int grp = tid >> g.log2nl;
     const int x0l = grp * SMC_PX, x0 = tx0 + x0l;
     const int d0 = s * SMC_DS;
+    if (x0 >= g.xlim) return;                      // (all lanes of a pixel group leave together)
     const int bL = g.pad + x0l - half;            // byte offset of the window in a staged row
     const int wL = bL >> 2, shL = bL & 3;
     const int bR = bL + d0;
@@ -242,15 +245,11 @@ static const void *cost_ptr(bool ssd, bool ghost)
                : (ghost ? (const void *)k_cost_wta<NWD, false, true> : (const void *)k_cost_wta<NWD, false, false>);
 }
 
-extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
-                           int cost, int pairs, int32_t *d_web, int32_t *d_best, void *stream)
+// the general (masked) kernel on the whole image, or -- strip_cols > 0 -- only on the pixel
+// columns [0, strip_cols) (the ghost-border columns the quad-SAD kernel cannot do)
+static int launch_general(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right, int cost,
+                          int pairs, int32_t *d_web, int32_t *d_best, int strip_cols, hipStream_t stream)
 {
-    if (!plan) return sm_fail(SM_ERR_ARG, "sm_cost_wta: plan is NULL");
-    if (pairs < 1 || pairs > plan->max_pairs)
-        return sm_fail(SM_ERR_ARG, "sm_cost_wta: pairs %d outside 1..%d", pairs, plan->max_pairs);
-    if (!d_gray_left || !d_gray_right || !d_web) return sm_fail(SM_ERR_ARG, "sm_cost_wta: NULL argument");
-    if (cost != SM_COST_SAD && cost != SM_COST_SSD)
-        return sm_fail(SM_ERR_ARG, "sm_cost_wta: cost %d is neither SM_COST_SAD nor SM_COST_SSD", cost);
     CostGeom g;
     g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
     g.half = plan->square_width / 2; g.n = 2 * g.half + 1;
@@ -268,6 +267,11 @@ extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint
     g.lrow = 4 * ((g.pad + g.tw + 4 * (nwd + 1) + 3) / 4);
     g.rrow = 4 * ((g.pad + g.tw + g.nl * SMC_DS + 4 * (nwd + 4) + 3) / 4);
     g.tiles_x = (g.w + g.tw - 1) / g.tw;
+    g.xlim = g.w;
+    if (strip_cols > 0) {
+        g.xlim = strip_cols;
+        g.tiles_x = (strip_cols + g.tw - 1) / g.tw;
+    }
     int th = 64;
     while (th > 8 && (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs < 1024) th >>= 1;
     while ((th + g.n - 1) * (g.lrow + g.rrow) > 60 * 1024 && th > 1) th >>= 1;
@@ -286,12 +290,41 @@ extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint
     case 6: fn = cost_ptr<6>(ssd, ghost); break;
     default: fn = cost_ptr<7>(ssd, ghost); break;
     }
-    hipError_t e = hipSetDevice(plan->device);
-    if (e == hipSuccess) {
-        void *args[] = {(void *)&d_gray_left, (void *)&d_gray_right, (void *)&d_web, (void *)&d_best, (void *)&g};
-        e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(256), args,
-                            (size_t)g.nsr * (g.lrow + g.rrow), (hipStream_t)stream);
-    }
+    void *args[] = {(void *)&d_gray_left, (void *)&d_gray_right, (void *)&d_web, (void *)&d_best, (void *)&g};
+    const hipError_t e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(256), args,
+                                         (size_t)g.nsr * (g.lrow + g.rrow), stream);
     if (e != hipSuccess) return sm_fail(SM_ERR_HIP, "sm_cost_wta: %s", hipGetErrorString(e));
     return SM_OK;
 }
+
+extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
+                           int cost, int pairs, int32_t *d_web, int32_t *d_best, void *stream)
+{
+    if (!plan) return sm_fail(SM_ERR_ARG, "sm_cost_wta: plan is NULL");
+    if (pairs < 1 || pairs > plan->max_pairs)
+        return sm_fail(SM_ERR_ARG, "sm_cost_wta: pairs %d outside 1..%d", pairs, plan->max_pairs);
+    if (!d_gray_left || !d_gray_right || !d_web) return sm_fail(SM_ERR_ARG, "sm_cost_wta: NULL argument");
+    if (cost != SM_COST_SAD && cost != SM_COST_SSD)
+        return sm_fail(SM_ERR_ARG, "sm_cost_wta: cost %d is neither SM_COST_SAD nor SM_COST_SSD", cost);
+    const hipError_t es = hipSetDevice(plan->device);
+    if (es != hipSuccess) return sm_fail(SM_ERR_HIP, "sm_cost_wta: %s", hipGetErrorString(es));
+    if (cost == SM_COST_SAD) {
+        SadGeom q;
+        const void *fn = sm_sad_qs_configure(plan, pairs, d_gray_left, d_gray_right, &q);
+        if (fn) {
+            void *args[] = {(void *)&d_gray_left, (void *)&d_gray_right, (void *)&d_web, (void *)&d_best, (void *)&q};
+            const hipError_t e = hipLaunchKernel(fn, dim3(q.tiles_x, q.tiles_y, pairs), dim3(64), args,
+                                                 (size_t)q.lds_bytes, (hipStream_t)stream);
+            if (e != hipSuccess) return sm_fail(SM_ERR_HIP, "sm_cost_wta: %s", hipGetErrorString(e));
+            // ghost border: the columns whose windows reach left of the image, by the masked kernel
+            if (q.ghost && plan->square_width / 2 > 0)
+                return launch_general(plan, d_gray_left, d_gray_right, cost, pairs, d_web, d_best,
+                                      plan->square_width / 2, (hipStream_t)stream);
+            return SM_OK;
+        }
+    }
+    return launch_general(plan, d_gray_left, d_gray_right, cost, pairs, d_web, d_best, 0, (hipStream_t)stream);
+}
+
+// tuning hook of tools/cost_mode_timing.py (not part of the boundary)
+extern "C" void sm_debug_cost_tune(int px, int tile_h) { sm_cost_qs_tune(px, tile_h); }

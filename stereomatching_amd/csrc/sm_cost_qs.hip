@@ -1,0 +1,359 @@
+// sm_cost_qs.hip -- SAD cost mode of the hot path on the quad-SAD unit.
+//
+// PARITY UNPINNED: the reference has no SAD implementation; the mode is
+// the build's own definition (oracle/stereo_oracle.c smo_cost_hot_path, see sm_cost.hip).
+//
+// v_qsad_pk_u16_u8 D, S0 (8 bytes), S1 (4 bytes), S2 (4 x u16) is a block-matching step:
+//     D.u16[i] = S2.u16[i] + sum_{j<4} | S0.byte[i+j] - S1.byte[j] |          i = 0..3
+// With S1 = four pixels of the left row and S0 = eight pixels of the right row starting at
+// x + d, one instruction adds the cost of that 4-pixel group for FOUR consecutive shifts
+// d .. d+3 to four packed 16-bit window sums.  It issues at a quarter of the plain VALU rate
+// (tools/ubench_sad.hip: 16.8 cycles alone, 12.7 per SIMD with two waves) -- the same
+// abs-differences per cycle as v_sad_u8, but the accumulate, the packing and the alignment to
+// the shift come for free.
+//
+// A lane owns PX pixels (4 apart) x 4*NQL shifts and keeps their window sums A as packed u16
+// (n*n*255 < 65536: windows up to 15 x 15).  Per output row and (pixel, 4 shifts):
+//     t = E;   t = qsad(old row groups ..., t)           NG = ceil(n/4) instructions
+//     A = qsad(new row groups ..., A)                    NG
+//     A -= t                                             2 x v_pk_sub_u16
+//     keys (A << 16 | shift), first-wins arg-min         4 + 2 x v_min3_u32
+// All 8-byte right-image operands are dword-ALIGNED: a pixel x only takes the shift quads that
+// start at d = -((x - half) mod 4) (mod 4), so no byte alignment is ever needed on the right row.
+// The left operands (shared by all shifts) are cut with v_alignbyte once per row.
+//
+// The last group of a window row holds n mod 4 pixels; the other bytes of the LEFT operand are
+// zeroed, which makes the instruction add the plain right bytes there: sum_{j >= r} R(p+i+j).
+// That term depends on the right row and the position only, so its difference between the row
+// that slides in and the row that slides out is computed once per row and right-image position
+// by the wave (E, via v_mqsad_pk_u16_u8 against a reference of 255s on exactly those bytes) and
+// enters as the INITIAL accumulator of the old row's chain: no VALU instruction is spent on it.
+//
+// Ghost border: rows / columns outside the image are staged as zeros in both images, which gives
+// the oracle's "no tap outside the image, zeros past the right border" -- except for taps LEFT of
+// the image (left = 0, right(x' + d) inside).  The columns x < half + 3 are therefore recomputed
+// by the masked kernel of sm_cost.hip (sm_cost_left_strip), a launch of a few workgroups.
+
+#include "sm_internal.h"
+#include "sm_cost.h"
+#include <type_traits>
+
+typedef unsigned long long u64;
+typedef unsigned short v4h __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u64 pk4_sub(u64 a, u64 b)
+{
+    return __builtin_bit_cast(u64, (v4h)(__builtin_bit_cast(v4h, a) - __builtin_bit_cast(v4h, b)));
+}
+__device__ __forceinline__ u64 qsad(u64 r8, u32 l4, u64 acc) { return __builtin_amdgcn_qsad_pk_u16_u8(r8, l4, acc); }
+
+// 8-byte LDS reads at 4-byte alignment (-> ds_read2_b32 into an even register pair)
+typedef u64 __attribute__((aligned(4))) u64a4;
+
+template <int N, int NQL, int PX>
+__global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, const u8 *__restrict__ right,
+                                                  i32 *__restrict__ web, i32 *__restrict__ best,
+                                                  const SadGeom g)
+{
+    constexpr int HALF = N / 2, FG = N / 4, RB = N % 4, NG = FG + 1;
+    constexpr u32 MASKR = RB == 1 ? 0x000000ffu : 0x00ffffffu;      // left bytes of the last group
+    constexpr u32 MASKC = ~MASKR;                                    // 255 on the bytes zeroed there
+    constexpr int WN = NG + PX - 1;                                  // right operands alive per quad
+    static_assert(RB == 1 || RB == 3, "odd windows");
+    static_assert(N * N * 255 < 65536, "window sums are packed 16-bit");
+
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.z;
+    const int xw = blockIdx.x * g.tw, ty0 = blockIdx.y * g.tile_h;
+    const size_t img = (size_t)pair * g.w * g.h;
+    const u8 *L = left + img, *R = right + img;
+    const int lw = g.lrow >> 2, rw = g.rrow >> 2;                    // dwords per staged row
+    u32 *sL = lds;                                                   // [nsr][lw]
+    u32 *sR = sL + g.nsr * lw;                                       // [nsr][rw]
+    u64 *sE = reinterpret_cast<u64 *>(sR + g.nsr * rw);              // [rw]: 4 x u16 per right dword
+
+    // ---- stage the tile's rows (+ window halo) with the border rule applied
+    for (int row = 0; row < g.nsr; row++) {
+        const int y = ty0 - HALF + row;
+        const bool vy = y >= 0 && y < g.h;
+        const int ys = g.ghost ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
+        for (int k = tid; k < lw + rw; k += 64) {
+            const bool is_r = k >= lw;
+            const int kk = is_r ? k - lw : k;
+            const int x = xw - g.padl + 4 * kk;
+            const u8 *src = (is_r ? R : L) + (size_t)ys * g.w;
+            u32 v = 0;
+            if (g.fast_stage) {                 // w % 4 == 0, rows dword-aligned: a dword never straddles a border
+                if (g.ghost) {
+                    if (vy && x >= 0 && x < g.w) v = *reinterpret_cast<const u32 *>(src + x);
+                } else {
+                    v = *reinterpret_cast<const u32 *>(src + ((x % g.w) + g.w) % g.w);
+                }
+            } else {
+                for (int b = 0; b < 4; b++) {
+                    const int xb = x + b;
+                    u32 p = 0;
+                    if (g.ghost) { if (vy && xb >= 0 && xb < g.w) p = src[xb]; }
+                    else p = src[((xb % g.w) + g.w) % g.w];
+                    v |= p << (8 * b);
+                }
+            }
+            (is_r ? sR + row * rw : sL + row * lw)[kk] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- lane role: residue a, shift-lane sl, pixel group j
+    const int a = tid & 3;
+    const int sl = (tid >> 2) & (g.nl - 1);
+    const int j = tid >> (2 + g.log2nl);
+    const int x0 = xw + 4 * PX * j + a;                 // pixel i of this lane: x0 + 4 i
+    const int rho = (a - HALF) & 3;                     // (x - HALF) mod 4
+    const int bL = (x0 - HALF - rho - (xw - g.padl)) >> 2;      // dword of the window's aligned start
+    const int bR = bL + sl * NQL;                       // ... of shift quad 0's right operand
+    const int dconst = 4 * sl * NQL - rho;              // shift of (quad 0, position 0)
+
+    u64 A[PX][NQL];
+#pragma unroll
+    for (int i = 0; i < PX; i++)
+#pragma unroll
+        for (int q = 0; q < NQL; q++) A[i][q] = 0;
+
+    auto ld_pair = [&](const u32 *row, int idx) -> u64 { return *reinterpret_cast<const u64a4 *>(row + idx); };
+
+    // one window row in (rn), one out (ro; none while WARM), optionally the arg-min of row y
+    auto step = [&](auto warm_tag, auto out_tag, int rn_i, int ro_i, int y) {
+        constexpr bool WARM = decltype(warm_tag)::value, OUT = decltype(out_tag)::value;
+        const u32 *rowLn = sL + rn_i * lw, *rowRn = sR + rn_i * rw;
+        const u32 *rowLo = sL + ro_i * lw, *rowRo = sR + ro_i * rw;
+
+        // E: per right dword position, (bytes the zeroed left bytes pick up in the new row) - (old row)
+        for (int k = tid; k < rw - 1; k += 64) {
+            const u64 mn = __builtin_amdgcn_mqsad_pk_u16_u8(ld_pair(rowRn, k), MASKC, 0ull);   // 255 (4-RB) - T_new
+            u64 e;
+            if (WARM) e = pk4_sub(0x0001000100010001ull * (255u * (4 - RB)), mn);
+            else e = pk4_sub(__builtin_amdgcn_mqsad_pk_u16_u8(ld_pair(rowRo, k), MASKC, 0ull), mn);
+            sE[k] = e;
+        }
+        __syncthreads();
+
+        // left operands of this lane's PX windows: NG groups each, 4 pixels apart -> NG + PX - 1 dwords
+        u32 un[WN], unp[PX], uo[WN], uop[PX];
+        {
+            u32 t[WN + 1];
+#pragma unroll
+            for (int m = 0; m <= WN; m++) t[m] = rowLn[bL + m];
+#pragma unroll
+            for (int m = 0; m < WN; m++) un[m] = __builtin_amdgcn_alignbyte(t[m + 1], t[m], rho);
+#pragma unroll
+            for (int i = 0; i < PX; i++) unp[i] = un[i + FG] & MASKR;
+            if (!WARM) {
+#pragma unroll
+                for (int m = 0; m <= WN; m++) t[m] = rowLo[bL + m];
+#pragma unroll
+                for (int m = 0; m < WN; m++) uo[m] = __builtin_amdgcn_alignbyte(t[m + 1], t[m], rho);
+#pragma unroll
+                for (int i = 0; i < PX; i++) uop[i] = uo[i + FG] & MASKR;
+            }
+        }
+
+        // Running minimum in two levels: within a chunk of CH quads the keys carry the shift relative
+        // to the chunk (0 .. 4 CH - 1: inline constants -- with the absolute shift in the key the
+        // compiler hoists a hundred scalar constants out of the row loop and spills scalar registers
+        // into vector ones); a finished chunk's winner gets its base added and enters the row's
+        // minimum.  0xffff0000 = "nothing yet" (a real sum is below 0xffff, and adding a base to it
+        // cannot wrap).
+        constexpr int CH = 16;
+        // (opaque copies: the 2 x NQL uniform comparisons below are otherwise computed once, outside
+        // the row loop, and kept in scalar registers -- more than there are)
+        int q_last = g.q_last, q_tail = g.q_tail;
+        asm volatile("" : "+s"(q_last), "+s"(q_tail));
+        int dc = dconst;                    // (the same for the per-lane validity tests of the checked quads)
+        asm volatile("" : "+v"(dc));
+        u32 run[PX], runc[PX];
+#pragma unroll
+        for (int i = 0; i < PX; i++) run[i] = 0xffffffffu;
+
+        // operands of quad q: right dwords bR + q + m (m < WN), E of bR + q + FG + i (i < PX).  The reads
+        // of quad q + 1 are issued at the top of quad q, and nothing moves across the scheduling
+        // barrier between quads: left alone the scheduler hoists the reads of ALL quads to the top
+        // of the row and spills hundreds of registers.
+        u64 rn[WN + 1], ro[WN + 1], ee[PX + 1];
+#pragma unroll
+        for (int m = 0; m < WN; m++) {
+            rn[m] = ld_pair(rowRn, bR + m);
+            if (!WARM) ro[m] = ld_pair(rowRo, bR + m);
+        }
+#pragma unroll
+        for (int i = 0; i < PX; i++) ee[i] = sE[bR + FG + i];
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int q = 0; q < NQL; q++) {
+            if (OUT && q % CH == 0) {
+#pragma unroll
+                for (int i = 0; i < PX; i++) runc[i] = 0xffff0000u;
+            }
+            if (q <= q_last) {              // uniform: beyond it no lane has a shift below D
+                if (q + 1 < NQL) {
+                    rn[WN] = ld_pair(rowRn, bR + q + WN);
+                    if (!WARM) ro[WN] = ld_pair(rowRo, bR + q + WN);
+                    ee[PX] = sE[bR + q + FG + PX];
+                }
+#pragma unroll
+                for (int i = 0; i < PX; i++) {
+                    u64 t = ee[i];
+                    if (!WARM) {
+#pragma unroll
+                        for (int gp = 0; gp < NG; gp++) t = qsad(ro[i + gp], gp == FG ? uop[i] : uo[i + gp], t);
+                    }
+                    u64 acc = A[i][q];
+#pragma unroll
+                    for (int gp = 0; gp < NG; gp++) acc = qsad(rn[i + gp], gp == FG ? unp[i] : un[i + gp], acc);
+                    acc = pk4_sub(acc, t);
+                    A[i][q] = acc;
+                    if (OUT) {
+                        // keys: window sum << 16 | shift within the chunk; the smallest wins, i.e. the
+                        // lowest sum and among equals the FIRST shift
+                        const int cq = 4 * (q % CH);
+                        const u32 lo = (u32)acc, hi = (u32)(acc >> 32);
+                        u32 k0 = (lo << 16) | (u32)cq, k1 = (lo & 0xffff0000u) | (u32)(cq + 1);
+                        u32 k2 = (hi << 16) | (u32)(cq + 2), k3 = (hi & 0xffff0000u) | (u32)(cq + 3);
+                        if (q == 0 || q >= q_tail) {      // uniform: shifts < 0 or >= D may be among these
+                            const u32 dlim = (u32)g.D;
+                            if ((u32)(dc + 4 * q) >= dlim) k0 = 0xffffffffu;
+                            if ((u32)(dc + 4 * q + 1) >= dlim) k1 = 0xffffffffu;
+                            if ((u32)(dc + 4 * q + 2) >= dlim) k2 = 0xffffffffu;
+                            if ((u32)(dc + 4 * q + 3) >= dlim) k3 = 0xffffffffu;
+                        }
+                        runc[i] = min(min(runc[i], k0), k1);
+                        runc[i] = min(min(runc[i], k2), k3);
+                        // (pinned: the compiler otherwise sinks the whole min chain to the end of the row
+                        // and keeps the keys of every quad alive until then)
+                        asm volatile("" : "+v"(runc[i]));
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < WN; m++) { rn[m] = rn[m + 1]; if (!WARM) ro[m] = ro[m + 1]; }
+#pragma unroll
+                for (int i = 0; i < PX; i++) ee[i] = ee[i + 1];
+            }
+            if (OUT && (q % CH == CH - 1 || q == NQL - 1)) {
+#pragma unroll
+                for (int i = 0; i < PX; i++) {
+                    run[i] = min(run[i], runc[i] + (u32)(4 * CH * (q / CH)));
+                    asm volatile("" : "+v"(run[i]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        if (OUT) {
+#pragma unroll
+            for (int i = 0; i < PX; i++) {
+                u32 key = run[i] + (u32)dconst;             // the low half becomes the shift itself (>= 0 for a winner)
+                for (int k = 0; k < g.log2nl; k++) key = min(key, (u32)__shfl_xor((int)key, 4 << k));
+                const int x = x0 + 4 * i;
+                if (sl == 0 && x < g.w) {
+                    const size_t o = ((size_t)pair * g.h + y) * g.w + x;
+                    web[o] = (i32)(key & 0xffffu) + 1;
+                    if (best) best[o] = (i32)(key >> 16);
+                }
+            }
+        }
+        __syncthreads();            // E is rewritten by the next step
+    };
+
+    const int rows_out = min(g.tile_h, g.h - ty0);
+    using T = std::true_type;
+    using F = std::false_type;
+    // staged row e is image row ty0 - HALF + e: output row t has window rows t .. t + N - 1
+#pragma unroll 1
+    for (int e = 0; e < N - 1; e++) step(T{}, F{}, e, 0, 0);
+    step(T{}, T{}, N - 1, 0, ty0);
+#pragma unroll 1
+    for (int t = 1; t < rows_out; t++) step(F{}, T{}, t + N - 1, t - 1, ty0 + t);
+}
+
+// ---------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------
+
+template <int N>
+static const void *sad_qs_ptr(int nql, int px)
+{
+    if (nql == 33 && px == 2) return (const void *)k_sad_qs<N, 33, 2>;
+    if (nql == 17 && px == 2) return (const void *)k_sad_qs<N, 17, 2>;
+    if (nql == 17 && px == 4) return (const void *)k_sad_qs<N, 17, 4>;
+    if (nql == 9 && px == 4) return (const void *)k_sad_qs<N, 9, 4>;
+    if (nql == 5 && px == 4) return (const void *)k_sad_qs<N, 5, 4>;
+    return nullptr;
+}
+
+static int g_tune_px = 0, g_tune_tile_h = 0;
+void sm_cost_qs_tune(int px, int tile_h) { g_tune_px = px; g_tune_tile_h = tile_h; }
+
+// fills g and returns the kernel, or nullptr if this shape is not built (caller falls back)
+const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *out)
+{
+    SadGeom g;
+    g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
+    const int half = plan->square_width / 2, n = 2 * half + 1;
+    g.ghost = plan->border == SM_GHOST;
+    if (n < 3 || n > 15 || g.D > 4 * 4 * 33 - 3) return nullptr;
+    const int nq = (g.D + 3 + 3) / 4;               // quads that cover shifts -3 .. D-1
+    int nql, px;
+    if (nq <= 5) { nql = 5; px = 4; }
+    else if (nq <= 9) { nql = 9; px = 4; }
+    else if (nq <= 17) { nql = 17; px = 4; }
+    else { nql = 33; px = 2; }
+    if (g_tune_px && nql == 17) px = g_tune_px;
+    g.nl = 1; g.log2nl = 0;
+    while (g.nl * nql < nq) { g.nl <<= 1; g.log2nl++; }
+    g.tw = 4 * px * (16 / g.nl);
+    g.tiles_x = (g.w + g.tw - 1) / g.tw;
+    const int ng = n / 4 + 1;
+    g.padl = 4 * ((half + 3 + 3) / 4);
+    // left row: dwords bL .. bL + NG + PX - 1 of the last pixel group; right: up to bR + NQL - 1 + NG + PX - 1 (+1 for the pair)
+    g.lrow = 8 * ((g.padl + g.tw + 4 * (ng + 1) + 7) / 8);
+    g.rrow = 8 * ((g.padl + g.tw + 4 * (g.nl * nql + ng + 2) + 7) / 8);
+    // last quad (of the last shift-lane) whose four shifts are all below D for every lane: rho <= 3
+    g.q_tail = (g.D - 4 * (g.nl - 1) * nql) / 4;
+    if (g.q_tail < 0) g.q_tail = 0;
+    // ... and the last quad that holds a shift below D for some lane (rho = 3); with several
+    // shift-lanes the lower ones need all their quads
+    g.q_last = g.nl > 1 ? nql - 1 : (g.D + 2) / 4;
+    if (g.q_last > nql - 1) g.q_last = nql - 1;
+    // tile height: whole rounds of two waves per SIMD; rows + warm-up + staging per workgroup
+    const int slots = 256 * 4 * 2;
+    int best_th = 0; double best_cost = 0;
+    for (int th = 8; th <= 128; th += 4) {
+        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + 2 * (size_t)g.rrow;
+        if (lds > 160 * 1024 / 8) break;
+        const long long tiles = (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs;
+        const long long rounds = (tiles + slots - 1) / slots;
+        const double cost = (double)rounds * (th + 0.45 * (n - 1) + 2.0);
+        if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
+    }
+    if (!best_th) return nullptr;
+    if (g_tune_tile_h) best_th = g_tune_tile_h;
+    g.tile_h = best_th < g.h ? best_th : g.h;
+    g.tiles_y = (g.h + g.tile_h - 1) / g.tile_h;
+    g.nsr = g.tile_h + n - 1;
+    g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0;
+    g.lds_bytes = g.nsr * (g.lrow + g.rrow) + 2 * g.rrow;
+    g.nql = nql; g.px = px;
+    const void *fn = nullptr;
+    switch (n) {
+    case 3: fn = sad_qs_ptr<3>(nql, px); break;
+    case 5: fn = sad_qs_ptr<5>(nql, px); break;
+    case 7: fn = sad_qs_ptr<7>(nql, px); break;
+    case 9: fn = sad_qs_ptr<9>(nql, px); break;
+    case 11: fn = sad_qs_ptr<11>(nql, px); break;
+    case 13: fn = sad_qs_ptr<13>(nql, px); break;
+    case 15: fn = sad_qs_ptr<15>(nql, px); break;
+    }
+    *out = g;
+    return fn;
+}

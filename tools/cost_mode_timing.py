@@ -1,16 +1,29 @@
-import sys, time
-sys.path.insert(0,'.')
+"""SAD / SSD cost mode (parity unpinned): time per launch at the BASELINE configurations.
+    python tools/cost_mode_timing.py [C2 C3 C5 ...]"""
+import sys
+sys.path.insert(0, '.')
 import torch
 from stereomatching_amd import pipeline
 from stereomatching_amd.synth import CONFIGS, make_pair
-for cfg in ("C2","C3"):
-    w,h,d,sw,mode = CONFIGS[cfg]
-    l,r = make_pair(w,h,d,seed=1)
-    L,R = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
-    plan = pipeline.StereoPlan(w,h,d,sw,mode)
-    for cost in ("sad","ssd"):
-        for _ in range(3): plan.cost_wta(L,R,cost,want_best=False)
-        torch.cuda.synchronize(); t0=time.perf_counter()
-        for _ in range(10): plan.cost_wta(L,R,cost,want_best=False)
-        torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/10
-        print(f"{cfg} {cost}: {dt*1e3:.3f} ms  {w*h*d/dt/1e6:.0f} Mpixel-disparities/s")
+
+cfgs = [a for a in sys.argv[1:] if a in CONFIGS] or ["C2", "C3", "C5"]
+for cfg in cfgs:
+    w, h, d, sw, mode = CONFIGS[cfg]
+    l, r = make_pair(w, h, d, seed=1)
+    L, R = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+    plan = pipeline.StereoPlan(w, h, d, sw, mode)
+    for cost in ("sad", "ssd"):
+        for _ in range(5):
+            plan.cost_wta(L, R, cost, want_best=False)
+        torch.cuda.synchronize()
+        n = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            plan.cost_wta(L, R, cost, want_best=False)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        print(f"{cfg} ({w}x{h}, {d} shifts, {sw}x{sw}, {mode}) {cost}: {ms:.3f} ms per launch, "
+              f"{w * h * d / ms / 1e3:.0f} Mpixel-disparities/s", flush=True)
+    plan.close()
