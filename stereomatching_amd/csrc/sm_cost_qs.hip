@@ -45,6 +45,8 @@ __device__ __forceinline__ u64 pk4_sub(u64 a, u64 b)
 {
     return __builtin_bit_cast(u64, (v4h)(__builtin_bit_cast(v4h, a) - __builtin_bit_cast(v4h, b)));
 }
+// (a & b) | c in one full-rate v_bitop3 (v_and_or_b32 is one of the half-rate class)
+__device__ __forceinline__ u32 bop_and_or(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); }
 __device__ __forceinline__ u64 qsad(u64 r8, u32 l4, u64 acc) { return __builtin_amdgcn_qsad_pk_u16_u8(r8, l4, acc); }
 
 // 8-byte LDS reads at 4-byte alignment (-> ds_read2_b32 into an even register pair)
@@ -74,23 +76,60 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
     u64 *sE = reinterpret_cast<u64 *>(sR + g.nsr * rw);              // [rw]: 4 x u16 per right dword
 
     // ---- stage the tile's rows (+ window halo) with the border rule applied
-    for (int row = 0; row < g.nsr; row++) {
-        const int y = ty0 - HALF + row;
-        const bool vy = y >= 0 && y < g.h;
-        const int ys = g.ghost ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
-        for (int k = tid; k < lw + rw; k += 64) {
+    if (g.fast_stage) {
+        // Image width a multiple of 4 and dword-aligned rows: a staged dword never straddles a border.
+        // A lane's dword columns are the same in every row, so the column arithmetic (the wrap-around
+        // or the border test) is done once, and the rows are loaded SR at a time with all loads in
+        // flight -- a load, a wait and a store per row and column cost a quarter of the kernel's
+        // instructions and left the wave waiting for memory 40 times over.
+        constexpr int SC = 4, SR = 4;                   // (lw + rw <= 256 dwords: checked by the host)
+        const u8 *col[SC];
+        int dst[SC], dstride[SC];
+        bool on[SC];
+#pragma unroll
+        for (int c = 0; c < SC; c++) {
+            const int k = tid + 64 * c;
             const bool is_r = k >= lw;
             const int kk = is_r ? k - lw : k;
             const int x = xw - g.padl + 4 * kk;
-            const u8 *src = (is_r ? R : L) + (size_t)ys * g.w;
-            u32 v = 0;
-            if (g.fast_stage) {                 // w % 4 == 0, rows dword-aligned: a dword never straddles a border
-                if (g.ghost) {
-                    if (vy && x >= 0 && x < g.w) v = *reinterpret_cast<const u32 *>(src + x);
-                } else {
-                    v = *reinterpret_cast<const u32 *>(src + ((x % g.w) + g.w) % g.w);
+            on[c] = k < lw + rw && (!g.ghost || (x >= 0 && x < g.w));
+            const int xs = g.ghost ? x : ((x % g.w) + g.w) % g.w;
+            col[c] = (is_r ? R : L) + (on[c] ? xs : 0);
+            dst[c] = is_r ? g.nsr * lw + kk : kk;
+            dstride[c] = is_r ? rw : lw;
+            if (k >= lw + rw) dst[c] = -1;
+        }
+        for (int row0 = 0; row0 < g.nsr; row0 += SR) {
+            u32 v[SR][SC];
+#pragma unroll
+            for (int r = 0; r < SR; r++) {
+                const int y = ty0 - HALF + row0 + r;
+                const bool vy = (y >= 0 && y < g.h) || !g.ghost;
+                const int ys = g.ghost ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
+#pragma unroll
+                for (int c = 0; c < SC; c++) {
+                    v[r][c] = 0;
+                    if (on[c] && vy && row0 + r < g.nsr)
+                        v[r][c] = *reinterpret_cast<const u32 *>(col[c] + (size_t)ys * g.w);
                 }
-            } else {
+            }
+#pragma unroll
+            for (int r = 0; r < SR; r++)
+#pragma unroll
+                for (int c = 0; c < SC; c++)
+                    if (dst[c] >= 0 && row0 + r < g.nsr) lds[dst[c] + (row0 + r) * dstride[c]] = v[r][c];
+        }
+    } else {
+        for (int row = 0; row < g.nsr; row++) {
+            const int y = ty0 - HALF + row;
+            const bool vy = y >= 0 && y < g.h;
+            const int ys = g.ghost ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
+            for (int k = tid; k < lw + rw; k += 64) {
+                const bool is_r = k >= lw;
+                const int kk = is_r ? k - lw : k;
+                const int x = xw - g.padl + 4 * kk;
+                const u8 *src = (is_r ? R : L) + (size_t)ys * g.w;
+                u32 v = 0;
                 for (int b = 0; b < 4; b++) {
                     const int xb = x + b;
                     u32 p = 0;
@@ -98,8 +137,8 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
                     else p = src[((xb % g.w) + g.w) % g.w];
                     v |= p << (8 * b);
                 }
+                (is_r ? sR + row * rw : sL + row * lw)[kk] = v;
             }
-            (is_r ? sR + row * rw : sL + row * lw)[kk] = v;
         }
     }
     __syncthreads();
@@ -161,19 +200,20 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
         // Running minimum in two levels: within a chunk of CH quads the keys carry the shift relative
         // to the chunk (0 .. 4 CH - 1: inline constants -- with the absolute shift in the key the
         // compiler hoists a hundred scalar constants out of the row loop and spills scalar registers
-        // into vector ones); a finished chunk's winner gets its base added and enters the row's
-        // minimum.  0xffff0000 = "nothing yet" (a real sum is below 0xffff, and adding a base to it
-        // cannot wrap).
-        constexpr int CH = 16;
+        // into vector ones); the chunks' winners get their bases added at the end of the row.
+        // 0xffff0000 = "nothing yet" (a real sum is below 0xffff, and adding a base cannot wrap).
+        constexpr int CH = 16, NCH = (NQL + CH - 1) / CH;
         // (opaque copies: the 2 x NQL uniform comparisons below are otherwise computed once, outside
         // the row loop, and kept in scalar registers -- more than there are)
         int q_last = g.q_last, q_tail = g.q_tail;
         asm volatile("" : "+s"(q_last), "+s"(q_tail));
         int dc = dconst;                    // (the same for the per-lane validity tests of the checked quads)
         asm volatile("" : "+v"(dc));
-        u32 run[PX], runc[PX];
+        u32 runc[NCH][PX];
 #pragma unroll
-        for (int i = 0; i < PX; i++) run[i] = 0xffffffffu;
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int i = 0; i < PX; i++) runc[c][i] = 0xffff0000u;
 
         // operands of quad q: right dwords bR + q + m (m < WN), E of bR + q + FG + i (i < PX).  The reads
         // of quad q + 1 are issued at the top of quad q, and nothing moves across the scheduling
@@ -189,13 +229,15 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
         for (int i = 0; i < PX; i++) ee[i] = sE[bR + FG + i];
         __builtin_amdgcn_sched_barrier(0);
 
-#pragma unroll
-        for (int q = 0; q < NQL; q++) {
-            if (OUT && q % CH == 0) {
-#pragma unroll
-                for (int i = 0; i < PX; i++) runc[i] = 0xffff0000u;
-            }
-            if (q <= q_last) {              // uniform: beyond it no lane has a shift below D
+        // The quads, each nested in the previous one's "q <= q_last" (uniform: beyond q_last no lane
+        // has a shift below D), so that leaving early is a jump to the end.  (Not a loop with a break,
+        // which the compiler does not unroll -- the sums would live in scratch memory -- and not a
+        // condition around each quad's body: the operand windows' rotation, a mere renaming in
+        // straight-line code, then becomes 300 register moves per row.)
+        auto quad = [&](auto self, auto qtag) __attribute__((always_inline)) -> void {
+            constexpr int q = decltype(qtag)::value;
+            if constexpr (q < NQL) {
+                if (q > q_last) return;
                 if (q + 1 < NQL) {
                     rn[WN] = ld_pair(rowRn, bR + q + WN);
                     if (!WARM) ro[WN] = ld_pair(rowRo, bR + q + WN);
@@ -212,41 +254,50 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
 #pragma unroll
                     for (int gp = 0; gp < NG; gp++) acc = qsad(rn[i + gp], gp == FG ? unp[i] : un[i + gp], acc);
                     acc = pk4_sub(acc, t);
+                    // (pinned: nothing of a quad may sink below the quads nested in it -- the compiler
+                    // otherwise reads all operands on the way in, spilling them, and computes on the way out)
+                    asm volatile("" : "+v"(acc));
                     A[i][q] = acc;
                     if (OUT) {
                         // keys: window sum << 16 | shift within the chunk; the smallest wins, i.e. the
                         // lowest sum and among equals the FIRST shift
-                        const int cq = 4 * (q % CH);
+                        constexpr int cq = 4 * (q % CH);
                         const u32 lo = (u32)acc, hi = (u32)(acc >> 32);
-                        u32 k0 = (lo << 16) | (u32)cq, k1 = (lo & 0xffff0000u) | (u32)(cq + 1);
-                        u32 k2 = (hi << 16) | (u32)(cq + 2), k3 = (hi & 0xffff0000u) | (u32)(cq + 3);
-                        if (q == 0 || q >= q_tail) {      // uniform: shifts < 0 or >= D may be among these
+                        u32 k0 = (lo << 16) | (u32)cq, k1 = bop_and_or(lo, 0xffff0000u, (u32)(cq + 1));
+                        u32 k2 = (hi << 16) | (u32)(cq + 2), k3 = bop_and_or(hi, 0xffff0000u, (u32)(cq + 3));
+                        if (q == 0 || q >= q_tail) {        // uniform: shifts < 0 or >= D may be among these
                             const u32 dlim = (u32)g.D;
                             if ((u32)(dc + 4 * q) >= dlim) k0 = 0xffffffffu;
                             if ((u32)(dc + 4 * q + 1) >= dlim) k1 = 0xffffffffu;
                             if ((u32)(dc + 4 * q + 2) >= dlim) k2 = 0xffffffffu;
                             if ((u32)(dc + 4 * q + 3) >= dlim) k3 = 0xffffffffu;
                         }
-                        runc[i] = min(min(runc[i], k0), k1);
-                        runc[i] = min(min(runc[i], k2), k3);
+                        u32 r = runc[q / CH][i];
+                        r = min(min(r, k0), k1);
+                        r = min(min(r, k2), k3);
                         // (pinned: the compiler otherwise sinks the whole min chain to the end of the row
                         // and keeps the keys of every quad alive until then)
-                        asm volatile("" : "+v"(runc[i]));
+                        asm volatile("" : "+v"(r));
+                        runc[q / CH][i] = r;
                     }
                 }
 #pragma unroll
                 for (int m = 0; m < WN; m++) { rn[m] = rn[m + 1]; if (!WARM) ro[m] = ro[m + 1]; }
 #pragma unroll
                 for (int i = 0; i < PX; i++) ee[i] = ee[i + 1];
+                __builtin_amdgcn_sched_barrier(0);
+                self(self, std::integral_constant<int, q + 1>{});
             }
-            if (OUT && (q % CH == CH - 1 || q == NQL - 1)) {
+        };
+        quad(quad, std::integral_constant<int, 0>{});
+        u32 run[PX];
+        if (OUT) {
 #pragma unroll
-                for (int i = 0; i < PX; i++) {
-                    run[i] = min(run[i], runc[i] + (u32)(4 * CH * (q / CH)));
-                    asm volatile("" : "+v"(run[i]));
-                }
+            for (int i = 0; i < PX; i++) {
+                run[i] = runc[0][i];
+#pragma unroll
+                for (int c = 1; c < NCH; c++) run[i] = min(run[i], runc[c][i] + (u32)(4 * CH * c));
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
 
         if (OUT) {
@@ -341,7 +392,8 @@ const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_le
     g.tile_h = best_th < g.h ? best_th : g.h;
     g.tiles_y = (g.h + g.tile_h - 1) / g.tile_h;
     g.nsr = g.tile_h + n - 1;
-    g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0;
+    g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0 &&
+                   g.lrow + g.rrow <= 4 * 256;
     g.lds_bytes = g.nsr * (g.lrow + g.rrow) + 2 * g.rrow;
     g.nql = nql; g.px = px;
     const void *fn = nullptr;

@@ -25,6 +25,8 @@ __global__ __launch_bounds__(64) void k_rate(u32 *out, u64 *info, int iters)
 {
     if (W == 1) asm volatile("" ::: "v250", "a16");
     if (W == 2) asm volatile("" ::: "v200");
+    if (W == 3) asm volatile("" ::: "v160");            // 136..168 registers: three waves per SIMD
+    if (W == 4) asm volatile("" ::: "v120");            // 104..128: four
     constexpr int ILP = 8;
     u64 a[ILP];
     typedef u32 v4u __attribute__((ext_vector_type(4)));
@@ -149,8 +151,8 @@ static u64 model(u64 s0, u32 s1, u64 s2, bool masked)
 int main()
 {
     u32 *out; u64 *info;
-    (void)hipMalloc(&out, 256 * 4 * 2 * 64 * sizeof(u32));
-    (void)hipMalloc(&info, 256 * 4 * 2 * sizeof(u64));
+    (void)hipMalloc(&out, 256 * 4 * 4 * 64 * sizeof(u32));
+    (void)hipMalloc(&info, 256 * 4 * 4 * sizeof(u64));
 
     // semantics first
     {
@@ -194,5 +196,7 @@ int main()
     both<OP_MINU32>(out, info); both<OP_MIN3>(out, info); both<OP_MADU16>(out, info); both<OP_ANDOR>(out, info);
     both<OP_LSHLOR>(out, info); both<OP_PERM>(out, info); both<OP_DOT4>(out, info); both<OP_ALIGNBYTE>(out, info);
     both<OP_PKMAD>(out, info); both<OP_SUBU32>(out, info); both<OP_QSAD_MIX>(out, info);
+    run<OP_QSAD, 3>(out, info); run<OP_QSAD, 4>(out, info); run<OP_QSAD_MIX, 3>(out, info); run<OP_QSAD_MIX, 4>(out, info);
+    run<OP_BITOP3, 3>(out, info); run<OP_BITOP3, 4>(out, info); run<OP_LSHLOR, 3>(out, info); run<OP_LSHLOR, 4>(out, info);
     return 0;
 }
