@@ -93,6 +93,29 @@ int sm_plan_create(int device, int width, int height, int num_shifts,
                    int square_width, int border, int max_pairs, sm_plan **out);
 void sm_plan_destroy(sm_plan *plan);
 
+/* The same with an explicit choice of kernel variant and tiling: what tuning runs, same-device
+ * A/B measurements and the tests that walk every built kernel need.  Every field 0 (or a NULL
+ * `options`) = the plan's own choice, which is what sm_plan_create takes; a choice that does not
+ * apply to the kernel the plan uses is ignored (sm_plan_describe / sm_plan_geometry say what was
+ * taken).  The library reads no environment variable.                                      */
+typedef struct sm_plan_options {
+    int struct_size;            /* sizeof(sm_plan_options) as the caller compiled it */
+    int kernel_family;          /* 1 = the popcount kernels (general fallback) even where the bit-sliced one is built */
+    int tile_h;                 /* match kernel: output rows per wave */
+    int shifts_per_lane;        /* bit-sliced kernel: 8 or 16 */
+    int workgroup_waves;        /* bit-sliced kernel: 1 = one-wave workgroups, 2 = two-wave workgroups (shared warm-up) */
+    int no_two_wave_cap;        /* 1 = never launch the variant capped at two waves per SIMD */
+    unsigned priority_pattern;  /* bit-sliced kernel: time-sliced wave priority, bit k = favoured slot parity in unit k */
+    int edge_kernel;            /* 1 = the one-pixel-per-lane edge kernel even where the four-pixel one applies */
+    int timing_by_records;      /* 1 = sm_plan_time_kernels brackets launches with event records instead of
+                                 *     reading the dispatch's own time stamps */
+    int cost_pixels_per_lane;   /* SAD kernel (sm_cost_wta): 2 or 4 where both are built */
+    int cost_tile_h;            /* SAD / SSD kernels: output rows per wave */
+    int cost_kernel;            /* 1 = the general masked kernel even where the quad-SAD / dot kernels apply */
+} sm_plan_options;
+int sm_plan_create_ex(int device, int width, int height, int num_shifts, int square_width,
+                      int border, int max_pairs, const sm_plan_options *options, sm_plan **out);
+
 /* human-readable description of the kernel variant and tiling the plan
  * selected (for logs / bench.py); the string lives as long as the plan */
 const char *sm_plan_describe(const sm_plan *plan);

@@ -46,6 +46,20 @@ class Geometry(C.Structure):
         "edge_rows_per_wave", "waves_per_workgroup")]
 
 
+class PlanOptions(C.Structure):
+    """sm_plan_options of include/stereo_hip.h (every field 0 = the plan's own choice)"""
+    _fields_ = [("struct_size", C.c_int), ("kernel_family", C.c_int), ("tile_h", C.c_int),
+                ("shifts_per_lane", C.c_int), ("workgroup_waves", C.c_int), ("no_two_wave_cap", C.c_int),
+                ("priority_pattern", C.c_uint), ("edge_kernel", C.c_int), ("timing_by_records", C.c_int),
+                ("cost_pixels_per_lane", C.c_int), ("cost_tile_h", C.c_int), ("cost_kernel", C.c_int)]
+
+    @classmethod
+    def make(cls, **kw):
+        o = cls(**kw)
+        o.struct_size = C.sizeof(cls)
+        return o
+
+
 _SIGNATURES = {
     "sm_last_error": (C.c_char_p, []),
     "sm_device_count": (_int, [_intp]),
@@ -66,6 +80,7 @@ _SIGNATURES = {
     "sm_stream_wait_event": (_int, [_int, _vp, _vp]),
     "sm_event_sync": (_int, [_int, _vp]),
     "sm_plan_create": (_int, [_int, _int, _int, _int, _int, _int, _int, C.POINTER(_vp)]),
+    "sm_plan_create_ex": (_int, [_int, _int, _int, _int, _int, _int, _int, C.POINTER(PlanOptions), C.POINTER(_vp)]),
     "sm_plan_destroy": (None, [_vp]),
     "sm_plan_describe": (C.c_char_p, [_vp]),
     "sm_plan_workspace_bytes": (_sz, [_vp]),

@@ -816,7 +816,16 @@ extern "C" int sm_event_sync(int device, void *event)
 extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
                               int square_width, int border, int max_pairs, sm_plan **out)
 {
+    return sm_plan_create_ex(device, width, height, num_shifts, square_width, border, max_pairs, nullptr, out);
+}
+
+extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shifts, int square_width,
+                                 int border, int max_pairs, const sm_plan_options *options, sm_plan **out)
+{
     if (!out) return sm_fail(SM_ERR_ARG, "sm_plan_create: out is NULL");
+    if (options && (options->struct_size < (int)sizeof(int) || options->struct_size > (int)sizeof(sm_plan_options)))
+        return sm_fail(SM_ERR_ARG, "sm_plan_create_ex: options->struct_size %d is not that of a sm_plan_options "
+                       "(this library: %d bytes)", options->struct_size, (int)sizeof(sm_plan_options));
     *out = nullptr;
     if (width < 1 || height < 1)
         return sm_fail(SM_ERR_ARG, "sm_plan_create: image size %dx%d is not positive", width, height);
@@ -842,6 +851,7 @@ extern "C" int sm_plan_create(int device, int width, int height, int num_shifts,
     p->width = width; p->height = height;
     p->num_shifts = num_shifts; p->square_width = square_width;
     p->border = border; p->max_pairs = max_pairs;
+    if (options) memcpy(&p->opt, options, (size_t)options->struct_size);     // a shorter (older) struct: the rest stays 0
     int rc = sm_match_configure(p);
     if (rc) { free(p); return rc; }
     p->g.web_bytes = 4;
@@ -1051,7 +1061,7 @@ extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
     // must be 4-byte aligned, else the any-width kernel takes over
     const bool aligned4 = (((uintptr_t)d_gray_left | (uintptr_t)d_gray_right |
                             (uintptr_t)d_edges_left | (uintptr_t)d_edges_right) & 3) == 0;
-    if (g.w % 4 == 0 && aligned4 && !getenv("SM_EDGES1")) {
+    if (g.w % 4 == 0 && aligned4 && plan->opt.edge_kernel != 1) {
         const int strips = (g.ext_rows + SM_EDGE4_ROWS - 1) / SM_EDGE4_ROWS;
         const int lanes = g.ext_words * 8;
         // waves side by side, unless that rounds the row up by more than 3 % (see the kernel)
@@ -1143,7 +1153,7 @@ extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int
     // (the completion signal's own start / end time stamps): no extra packets on the stream.
     // Separate event records cost ~4 us each there, 6 % of a 4K step when every second launch
     // is timed (bench.py at --steps 20).  Other kernels keep the bracketing records.
-    const bool attach = timed && plan->kernel == SM_KERNEL_BS && !via_tmp && !getenv("SM_TIMING_RECORDS");
+    const bool attach = timed && plan->kernel == SM_KERNEL_BS && !via_tmp && !plan->opt.timing_by_records;
     if (timed && !attach) SM_HIP(hipEventRecord(plan->t_begin[plan->timing_n], (hipStream_t)stream));
     plan->launch_ev_begin = attach ? plan->t_begin[plan->timing_n] : nullptr;
     plan->launch_ev_end = attach ? plan->t_end[plan->timing_n] : nullptr;

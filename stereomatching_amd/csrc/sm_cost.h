@@ -21,4 +21,3 @@ struct SadGeom {
 
 // sm_cost_qs.hip: fills *g and returns the kernel for this plan, or nullptr if the shape is not built
 const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
-void sm_cost_qs_tune(int px, int tile_h);      // tuning hook of tools/ (0 = the plan's own choice)

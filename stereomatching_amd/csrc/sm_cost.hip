@@ -325,6 +325,3 @@ extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint
     }
     return launch_general(plan, d_gray_left, d_gray_right, cost, pairs, d_web, d_best, 0, (hipStream_t)stream);
 }
-
-// tuning hook of tools/cost_mode_timing.py (not part of the boundary)
-extern "C" void sm_debug_cost_tune(int px, int tile_h) { sm_cost_qs_tune(px, tile_h); }

@@ -1,7 +1,7 @@
 // sm_cost_qs.hip -- SAD cost mode of the hot path on the quad-SAD unit.
 //
 // PARITY UNPINNED: the reference has no SAD implementation; the mode is
-// the build's own definition (oracle/stereo_oracle.c smo_cost_hot_path, see sm_cost.hip).
+// the build's own definition (stated at the top of sm_cost.hip; the checker restates it on the CPU).
 //
 // v_qsad_pk_u16_u8 D, S0 (8 bytes), S1 (4 bytes), S2 (4 x u16) is a block-matching step:
 //     D.u16[i] = S2.u16[i] + sum_{j<4} | S0.byte[i+j] - S1.byte[j] |          i = 0..3
@@ -31,8 +31,8 @@
 //
 // Ghost border: rows / columns outside the image are staged as zeros in both images, which gives
 // the oracle's "no tap outside the image, zeros past the right border" -- except for taps LEFT of
-// the image (left = 0, right(x' + d) inside).  The columns x < half + 3 are therefore recomputed
-// by the masked kernel of sm_cost.hip (sm_cost_left_strip), a launch of a few workgroups.
+// the image (left = 0, right(x' + d) inside).  The columns x < half are therefore recomputed
+// by the masked kernel of sm_cost.hip (launch_general with strip_cols), a launch of a few workgroups.
 
 #include "sm_internal.h"
 #include "sm_cost.h"
@@ -342,9 +342,6 @@ static const void *sad_qs_ptr(int nql, int px)
     return nullptr;
 }
 
-static int g_tune_px = 0, g_tune_tile_h = 0;
-void sm_cost_qs_tune(int px, int tile_h) { g_tune_px = px; g_tune_tile_h = tile_h; }
-
 // fills g and returns the kernel, or nullptr if this shape is not built (caller falls back)
 const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *out)
 {
@@ -352,14 +349,14 @@ const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_le
     g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
     const int half = plan->square_width / 2, n = 2 * half + 1;
     g.ghost = plan->border == SM_GHOST;
-    if (n < 3 || n > 15 || g.D > 4 * 4 * 33 - 3) return nullptr;
+    if (n < 3 || n > 15 || g.D > 4 * 4 * 33 - 3 || plan->opt.cost_kernel == 1) return nullptr;
     const int nq = (g.D + 3 + 3) / 4;               // quads that cover shifts -3 .. D-1
     int nql, px;
     if (nq <= 5) { nql = 5; px = 4; }
     else if (nq <= 9) { nql = 9; px = 4; }
     else if (nq <= 17) { nql = 17; px = 4; }
     else { nql = 33; px = 2; }
-    if (g_tune_px && nql == 17) px = g_tune_px;
+    if (plan->opt.cost_pixels_per_lane && nql == 17) px = plan->opt.cost_pixels_per_lane;
     g.nl = 1; g.log2nl = 0;
     while (g.nl * nql < nq) { g.nl <<= 1; g.log2nl++; }
     g.tw = 4 * px * (16 / g.nl);
@@ -388,7 +385,7 @@ const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_le
         if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
     }
     if (!best_th) return nullptr;
-    if (g_tune_tile_h) best_th = g_tune_tile_h;
+    if (plan->opt.cost_tile_h > 0) best_th = plan->opt.cost_tile_h;
     g.tile_h = best_th < g.h ? best_th : g.h;
     g.tiles_y = (g.h + g.tile_h - 1) / g.tile_h;
     g.nsr = g.tile_h + n - 1;

@@ -64,6 +64,7 @@ struct MatchGeom {
 
 struct sm_plan {
     int device;
+    sm_plan_options opt;     // sm_plan_create_ex: explicit variant choices (all 0 = the plan's own)
     int width, height, num_shifts, square_width, border, max_pairs;
     int kernel;          // SM_KERNEL_*
     MatchGeom g;

@@ -484,12 +484,11 @@ int sm_match_configure(sm_plan *plan)
     else if (g.n <= 16) kernel = SM_KERNEL_B;
     else kernel = SM_KERNEL_C;
     // the bit-sliced kernel where it is built (common windows, D <= 512);
-    // SM_KERNEL=popcount keeps the general kernels (A/B testing)
+    // sm_plan_options.kernel_family = 1 keeps the general kernels (A/B testing)
     const bool ghost = plan->border == SM_GHOST;
     auto nl_for = [&](int ds, int &log2nl) { int nl = 1; log2nl = 0; while (nl * ds < D) { nl <<= 1; log2nl++; } return nl; };
     {
-        const char *force = getenv("SM_KERNEL");
-        const bool want_bs = !(force && !strcmp(force, "popcount"));
+        const bool want_bs = plan->opt.kernel_family != 1;
         int l2;
         const int ds0 = sm_bs_default_ds(g.n);
         if (want_bs && kernel != SM_KERNEL_GENERIC && ds0 && nl_for(ds0, l2) <= 32)
@@ -518,8 +517,8 @@ int sm_match_configure(sm_plan *plan)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
-        if (const char *e = getenv("SM_TILE_H")) th_env = atoi(e);   // tuning / tests only
-        if (const char *e = getenv("SM_DS")) ds_env = atoi(e);
+        th_env = plan->opt.tile_h;              // sm_plan_create_ex: tuning / tests only
+        ds_env = plan->opt.shifts_per_lane;
     }
 
     // ---- geometry for `ds` shifts per lane, with the tile height chosen by a cost
@@ -620,7 +619,7 @@ int sm_match_configure(sm_plan *plan)
             const int cap = (int)((tiles + cus - 1) / cus);
             const void *kcap = sm_bs_kernel_ptr(o.n, ds, fulld, ghost, true, duo);
             const void *kuse = kfn;
-            if (kcap && cap <= 8 && !getenv("SM_NO_CAP2")) { o.cap2 = 1; kuse = kcap; }
+            if (kcap && cap <= 8 && !plan->opt.no_two_wave_cap) { o.cap2 = 1; kuse = kcap; }
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kuse, o.threads, o.lds_bytes) == hipSuccess
                 && cap >= 2 && cap < per_cu) {
@@ -642,7 +641,7 @@ int sm_match_configure(sm_plan *plan)
 
     // shifts per lane: 16 for the popcount kernels; for the bit-sliced kernel what is
     // built for this window (16 where it exists: measured faster than 8, fewer shared
-    // views and merge levels), SM_DS overrides for tuning
+    // views and merge levels), sm_plan_options.shifts_per_lane overrides for tuning
     int ds = 16;
     MatchGeom gsel;
     int rws = 0;
@@ -650,9 +649,9 @@ int sm_match_configure(sm_plan *plan)
     // per wave instead of N, for an exchange through LDS.  Measured on one device at the same
     // tile height (tools/ab_duo.sh): C3 95.3 -> 92.1 us, C4 x 8 83.6 -> 80.5, C5 197.9 -> 185.9,
     // C2 20.5 -> 19.4, 21 x 21 at 4K 88.5 -> 77.4, C1 9.9 -> 10.0: taken wherever the cost
-    // model says so (SM_DUO=0/1 overrides: tuning, tests).
+    // model says so (sm_plan_options.workgroup_waves overrides: tuning, tests).
     int duo_env = -1;
-    if (const char *e = getenv("SM_DUO")) duo_env = atoi(e) != 0;
+    if (plan->opt.workgroup_waves) duo_env = plan->opt.workgroup_waves == 2;
     auto duo_built = [&](int d) {
         int l2;
         return sm_bs_kernel_ptr(g.n, d, nl_for(d, l2) * d == D, ghost, false, true) != nullptr;
@@ -692,7 +691,7 @@ int sm_match_configure(sm_plan *plan)
     configure_best(ds, gsel, rws);
     g = gsel;
     g.prio_pattern = sm_bs_default_pattern(g.duo != 0);
-    if (const char *e = getenv("SM_PATTERN")) g.prio_pattern = (unsigned)strtoul(e, nullptr, 16);   // tuning
+    if (plan->opt.priority_pattern) g.prio_pattern = plan->opt.priority_pattern;   // tuning
 
     snprintf(plan->describe, sizeof plan->describe,
              "%s (n=%d, D=%d, %s): tile %dx%d px, %d threads "

@@ -45,15 +45,18 @@ class StereoPlan:
 
     def __init__(self, width: int, height: int, num_shifts: int = NUM_SHIFTS,
                  square_width: int = DEFAULT_SQUARE_WIDTH, border: str | int = "toroidal",
-                 max_pairs: int = 1, device: int = 0):
+                 max_pairs: int = 1, device: int = 0, options: dict | None = None):
+        """options: fields of sm_plan_options (kernel variant / tiling chosen explicitly:
+        tuning, A/B measurements, tests); None = the plan's own choices"""
         self.width, self.height = int(width), int(height)
         self.num_shifts, self.square_width = int(num_shifts), int(square_width)
         self.border = BORDERS[border] if isinstance(border, str) else int(border)
         self.max_pairs, self.device = int(max_pairs), int(device)
         self._h = C.c_void_p(0)
-        check(lib.sm_plan_create(self.device, self.width, self.height, self.num_shifts,
-                                 self.square_width, self.border, self.max_pairs,
-                                 C.byref(self._h)))
+        opts = capi.PlanOptions.make(**options) if options else None
+        check(lib.sm_plan_create_ex(self.device, self.width, self.height, self.num_shifts,
+                                    self.square_width, self.border, self.max_pairs,
+                                    C.byref(opts) if opts is not None else None, C.byref(self._h)))
         self._dev = torch.device("cuda", self.device)
 
     def close(self):

@@ -251,6 +251,32 @@ def hot_path_banded(le, re, num_shifts, square_width, mode="toroidal", n_bands=6
     return best, web
 
 
+def cost_hot_path_banded(left, right, num_shifts, square_width, mode="toroidal", cost="sad", n_bands=64,
+                         threads=None):
+    """cost_hot_path() of a large image, band by band (as hot_path_banded)"""
+    h, w = left.shape
+    half = square_width // 2
+    threads = threads or min(32, os.cpu_count() or 1)
+    best = np.zeros((h, w), np.int32)
+    web = np.zeros((h, w), np.int32)
+
+    def job(y0, y1):
+        def run():
+            if mode == "toroidal":
+                rows = np.arange(y0 - half, y1 + half) % h
+                lo = half
+            else:
+                a, b = max(0, y0 - half), min(h, y1 + half)
+                rows = np.arange(a, b)
+                lo = y0 - a
+            ob, ow = cost_hot_path(left[rows], right[rows], num_shifts, square_width, mode, cost)
+            best[y0:y1] = ob[lo:lo + y1 - y0]
+            web[y0:y1] = ow[lo:lo + y1 - y0]
+        return run
+    _run_threads([job(a, b) for a, b in _bands(h, n_bands)], threads)
+    return best, web
+
+
 def find_all_edges_banded(gray, threshold=0.15, mode="toroidal", n_bands=32, threads=None):
     h, w = gray.shape
     threads = threads or min(32, os.cpu_count() or 1)

@@ -27,9 +27,9 @@ def rand_edges(w, h, seed, density=0.5):
             (rng.random((h, w)) < density).astype(np.uint8))
 
 
-def hip_hot_path(hip, le, re, d, sw, mode, pairs=1):
+def hip_hot_path(hip, le, re, d, sw, mode, pairs=1, options=None):
     h, w = le.shape[-2:]
-    plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
+    plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=pairs, options=options)
     plan.load_edges(dev(le), dev(re))
     web, best = plan.match_wta(pairs, want_best=True)
     torch.cuda.synchronize()
@@ -379,35 +379,33 @@ def test_baseline_config_full_size_properties(hip, cfg):
 # non-default code paths (selected by environment at plan creation)
 # ---------------------------------------------------------------------------
 
-@pytest.fixture
-def env(monkeypatch):
-    def setter(**kw):
-        for k, v in kw.items():
-            monkeypatch.setenv(k, str(v))
-    return setter
+# kernel variants are chosen through sm_plan_create_ex (sm_plan_options); the library reads no
+# environment variable
+POPCOUNT = dict(kernel_family=1)
+DS8 = dict(shifts_per_lane=8)
+ONE_WAVE, TWO_WAVES = dict(workgroup_waves=1), dict(workgroup_waves=2)
+NO_CAP2 = dict(no_two_wave_cap=1)
 
 
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 @pytest.mark.parametrize("w,h,d,sw", [(300, 150, 128, 9), (71, 53, 30, 5), (130, 70, 64, 7), (90, 61, 64, 11)])
-@pytest.mark.parametrize("variant", [dict(SM_KERNEL="popcount"), dict(SM_DS=8), dict(SM_TILE_H=5),
-                                     dict(SM_DS=8, SM_TILE_H=7), dict(SM_NO_CAP2=1),
-                                     dict(SM_DUO=0), dict(SM_DUO=0, SM_TILE_H=5), dict(SM_DUO=0, SM_DS=8),
-                                     dict(SM_DUO=1, SM_TILE_H=5), dict(SM_DUO=1, SM_DS=8, SM_TILE_H=7)])
-def test_alternative_kernels_match_oracle(hip, env, variant, mode, w, h, d, sw):
+@pytest.mark.parametrize("variant", [POPCOUNT, DS8, dict(tile_h=5), dict(DS8, tile_h=7), NO_CAP2,
+                                     ONE_WAVE, dict(ONE_WAVE, tile_h=5), dict(ONE_WAVE, **DS8),
+                                     dict(TWO_WAVES, tile_h=5), dict(TWO_WAVES, tile_h=7, **DS8)])
+def test_alternative_kernels_match_oracle(hip, variant, mode, w, h, d, sw):
     """the popcount kernels (general fallback), the 8-shifts-per-lane bit-sliced
     variant and odd tile heights give the same bits as the default path"""
-    env(**variant)
     le, re = rand_edges(w, h, seed=w + d)
-    best, web, desc = hip_hot_path(hip, le, re, d, sw, mode)
-    if "SM_DUO" in variant:
-        assert ("two-wave workgroups" in desc) == bool(variant["SM_DUO"]), desc
-    if "SM_KERNEL" in variant:
+    best, web, desc = hip_hot_path(hip, le, re, d, sw, mode, options=variant)
+    if "workgroup_waves" in variant:
+        assert ("two-wave workgroups" in desc) == (variant["workgroup_waves"] == 2), desc
+    if "kernel_family" in variant:
         assert "tiled kernel" in desc
-    elif "SM_DS" in variant and sw in (8, 9):       # the 8-per-lane variant is built for 9x9
+    elif "shifts_per_lane" in variant and sw in (8, 9):       # the 8-per-lane variant is built for 9x9
         assert "lanes of 8" in desc
-    elif "SM_NO_CAP2" in variant:                   # small grids default to the 2-wave variant
+    elif "no_two_wave_cap" in variant:              # small grids default to the 2-wave variant
         assert "2 waves/SIMD variant" not in desc
-    elif variant.get("SM_DUO") == 0 and "SM_TILE_H" in variant and sw in (5, 7) and "SM_DS" not in variant:
+    elif variant.get("workgroup_waves") == 1 and "tile_h" in variant and sw in (5, 7) and "shifts_per_lane" not in variant:
         assert "2 waves/SIMD variant" in desc
     obest, oweb = oracle.hot_path(le, re, d, sw, mode)
     assert np.array_equal(web[0], oweb), desc
@@ -417,17 +415,16 @@ def test_alternative_kernels_match_oracle(hip, env, variant, mode, w, h, d, sw):
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 @pytest.mark.parametrize("sw,d", [(3, 16), (5, 30), (7, 64), (9, 128), (11, 100), (13, 24), (17, 64), (21, 30)])
 @pytest.mark.parametrize("h,tile_h", [(1, 4), (2, 4), (3, 2), (9, 4), (16, 4), (17, 4), (23, 3), (40, 16), (57, 8)])
-def test_two_wave_workgroups_match_oracle(hip, env, mode, sw, d, h, tile_h):
+def test_two_wave_workgroups_match_oracle(hip, mode, sw, d, h, tile_h):
     """k_match_bs<..., DUO>: the workgroup's two waves slide away from the tile's middle row
     and swap half of their first window through LDS.  Every window that is built, image
     heights around the tile boundaries (the last workgroup's lower wave with no rows at all,
     with some, with all; images shorter than one tile), both borders,
     shift counts that fill the lanes and that do not."""
-    env(SM_DUO=1, SM_TILE_H=tile_h)
     w = 100 + 3 * sw
     h = max(h, sw)              # the reference's rule: the window must fit the image
     le, re = rand_edges(w, h, seed=h * 31 + sw)
-    best, web, desc = hip_hot_path(hip, le, re, d, sw, mode)
+    best, web, desc = hip_hot_path(hip, le, re, d, sw, mode, options=dict(TWO_WAVES, tile_h=tile_h))
     assert "two-wave workgroups" in desc, desc
     obest, oweb = oracle.hot_path(le, re, d, sw, mode)
     assert np.array_equal(web[0], oweb), desc
@@ -459,9 +456,9 @@ BUILT_BS = [(n, 16) for n in (3, 5, 7, 9, 11)] + [(n, 8) for n in range(3, 22, 2
 
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 @pytest.mark.parametrize("fulld", [True, False])
-@pytest.mark.parametrize("shape", [dict(SM_DUO=0), dict(SM_DUO=0, SM_NO_CAP2=1), dict(SM_DUO=1)])
+@pytest.mark.parametrize("shape", [ONE_WAVE, dict(ONE_WAVE, **NO_CAP2), TWO_WAVES])
 @pytest.mark.parametrize("n,ds", BUILT_BS)
-def test_every_built_kernel_matches_oracle(hip, env, n, ds, shape, fulld, mode):
+def test_every_built_kernel_matches_oracle(hip, n, ds, shape, fulld, mode):
     """Every instantiation of k_match_bs the library holds -- window x shifts per lane x
     {shift range fills the lanes, does not} x border x {one wave, one wave capped at two
     per SIMD, two-wave workgroups} -- on tiles of 4 rows, i.e. with three slides per wave:
@@ -469,14 +466,14 @@ def test_every_built_kernel_matches_oracle(hip, env, n, ds, shape, fulld, mode):
     two largest ghost windows wrong from the third row of a tile on -- registers spilled
     between an inline-asm read and its wait -- while every test used the default tile
     height of 2 rows that such small images get.)"""
-    env(SM_DS=ds, SM_TILE_H=4, **shape)
+    duo = shape["workgroup_waves"] == 2
     d = 2 * ds if fulld else 2 * ds - 3
     w, h = 150, n + 10
     le, re = rand_edges(w, h, seed=n * 100 + ds)
-    best, web, desc = hip_hot_path(hip, le, re, d, n, mode)
-    assert f"lanes of {ds})" in desc and f"x{8 if shape['SM_DUO'] else 4} px" in desc, desc
-    assert ("two-wave workgroups" in desc) == bool(shape["SM_DUO"]), desc
-    if "SM_NO_CAP2" in shape:
+    best, web, desc = hip_hot_path(hip, le, re, d, n, mode, options=dict(shape, shifts_per_lane=ds, tile_h=4))
+    assert f"lanes of {ds})" in desc and f"x{8 if duo else 4} px" in desc, desc
+    assert ("two-wave workgroups" in desc) == duo, desc
+    if "no_two_wave_cap" in shape:
         assert "2 waves/SIMD variant" not in desc, desc
     obest, oweb = oracle.hot_path(le, re, d, n, mode)
     assert np.array_equal(web[0], oweb), desc
@@ -484,10 +481,10 @@ def test_every_built_kernel_matches_oracle(hip, env, n, ds, shape, fulld, mode):
 
 
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
-def test_one_pixel_edge_kernel(hip, env, mode):
-    env(SM_EDGES1=1)        # the kernel used when the width is not a multiple of 4
+def test_one_pixel_edge_kernel(hip, mode):
     left, right = make_pair(128, 66, 16, seed=4)
-    plan = hip.StereoPlan(128, 66, 16, 5, mode)
+    # (the kernel used when the width is not a multiple of 4)
+    plan = hip.StereoPlan(128, 66, 16, 5, mode, options=dict(edge_kernel=1))
     el, er = plan.find_all_edges(dev(left), dev(right), 0.15)
     assert np.array_equal(host(el)[0], oracle.find_all_edges(left, 0.15, mode))
     assert np.array_equal(host(er)[0], oracle.find_all_edges(right, 0.15, mode))
@@ -665,6 +662,76 @@ def test_cost_mode_matches_own_oracle(hip, mode, cost, w, h, d, sw):
     ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, cost)
     assert np.array_equal(host(web)[0], ow), (cost, mode)
     assert np.array_equal(host(best)[0], ob), (cost, mode)
+    plan.close()
+
+
+SAD_QS = [  # (w, h, D, S): quads per lane / shift-lanes / pixels per lane of the quad-SAD kernel
+    (64, 40, 16, 5),        # 5 quads
+    (131, 67, 30, 9),       # 9 quads, width not a multiple of 4 (bytewise staging)
+    (96, 70, 64, 7),        # 17 quads
+    (200, 50, 128, 9),      # 33 quads, the headline geometry
+    (300, 41, 256, 11),     # 2 shift-lanes of 33 quads
+    (132, 36, 500, 3),      # 4 shift-lanes, 3x3 (no full group), D > W
+    (260, 33, 100, 13),     # 33 quads of which the last 8 hold no shift below D (early exit)
+    (72, 45, 140, 15),      # 2 shift-lanes, the lower one full, the upper one mostly empty; 15x15
+    (40, 30, 17, 5),        # D = 4 k + 1
+    (16, 12, 3, 3),         # tiny
+]
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("tile_h", [0, 3])
+@pytest.mark.parametrize("w,h,d,sw", SAD_QS)
+def test_quad_sad_kernel_matches_own_oracle(hip, mode, tile_h, w, h, d, sw):
+    """k_sad_qs: every shape of (quads per lane, shift-lanes), windows 3 .. 15, both borders, tiles of
+    3 rows (several slides per wave, a ragged last tile) and the plan's own height, unaligned input"""
+    left, right = make_pair(w, h, d, seed=w * 3 + d, kind="noise" if (w + d) % 3 == 0 else "scene")
+    if (w + h) % 2:             # saturate some pixels: 0 and 255 are the masked-SAD corner cases
+        left[::3, ::5] = 0; left[1::4, 2::7] = 255; right[::5, ::3] = 255; right[2::3, 1::4] = 0
+    plan = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_tile_h=tile_h))
+    web, best = plan.cost_wta(dev(left), dev(right), "sad")
+    ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, "sad")
+    assert np.array_equal(host(web)[0], ow), (mode, w, h, d, sw)
+    assert np.array_equal(host(best)[0], ob), (mode, w, h, d, sw)
+    # the general masked kernel (what SSD and windows beyond 15 x 15 use) on the same input
+    gen = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_kernel=1))
+    web2, best2 = gen.cost_wta(dev(left), dev(right), "sad")
+    assert torch.equal(web2, web) and torch.equal(best2, best)
+    plan.close(); gen.close()
+
+
+def test_quad_sad_unaligned_images_and_batches(hip):
+    """image pointers that are not dword-aligned take the bytewise staging path; pairs of a batch
+    are independent launches in z"""
+    w, h, d, sw, n = 120, 50, 64, 9, 3
+    pairs = [make_pair(w, h, d, seed=90 + i) for i in range(n)]
+    left = np.stack([p[0] for p in pairs]); right = np.stack([p[1] for p in pairs])
+    plan = hip.StereoPlan(w, h, d, sw, "toroidal", max_pairs=n)
+    web, best = plan.cost_wta(dev(left), dev(right), "sad")
+    buf_l = torch.empty(n * w * h + 1, dtype=torch.uint8, device="cuda")
+    buf_r = torch.empty(n * w * h + 3, dtype=torch.uint8, device="cuda")
+    ul, ur = buf_l[1:].view(n, h, w), buf_r[3:].view(n, h, w)
+    ul.copy_(dev(left)); ur.copy_(dev(right))
+    web_u, best_u = plan.cost_wta(ul, ur, "sad")
+    for i in range(n):
+        ob, ow = oracle.cost_hot_path(pairs[i][0], pairs[i][1], d, sw, "toroidal", "sad")
+        assert np.array_equal(host(web)[i], ow) and np.array_equal(host(best)[i], ob), i
+    assert torch.equal(web_u, web) and torch.equal(best_u, best)
+    plan.close()
+
+
+@pytest.mark.parametrize("cfg,cost", [("C3", "sad"), ("C5", "sad"), ("C5", "ssd")])
+def test_cost_mode_4k_full_image_vs_own_oracle(hip, cfg, cost):
+    """The 4K configurations in the SAD / SSD cost mode (PARITY UNPINNED: the build's own CPU
+    definition is the only oracle), EVERY pixel of web and best: the definition run on row bands
+    with a window halo, in threads."""
+    w, h, d, sw, mode = CONFIGS[cfg]
+    left, right = make_pair(w, h, d, seed=3)
+    plan = hip.StereoPlan(w, h, d, sw, mode)
+    web, best = plan.cost_wta(dev(left), dev(right), cost)
+    ob, ow = oracle.cost_hot_path_banded(left, right, d, sw, mode, cost)
+    assert np.array_equal(host(web)[0], ow), (cfg, cost)
+    assert np.array_equal(host(best)[0], ob), (cfg, cost)
     plan.close()
 
 

@@ -37,23 +37,22 @@ for so in sorted((ROOT / "stereomatching_amd" / "variants").glob("*.so")):
         for spec in os.environ["AB_ENVS"].split(";"):
             envs_of = dict(kv.split("=") for kv in spec.split(","))     # "A=1,B=2": both at once
             entries.append((f"{so.stem}@{spec}", so, envs_of))
+from tools._options import struct_from_spec  # noqa: E402
+
 for name_, so, envs in entries:
-    for k, v in envs.items():
-        os.environ[k] = v
     lib = C.CDLL(str(so))
     lib.sm_last_error.restype = C.c_char_p
     lib.sm_find_edges.argtypes = [vp, vp, vp, C.c_double, C.c_int, vp, vp, vp]
     lib.sm_match_wta.argtypes = [vp, C.c_int, vp, vp, vp]
     plan = vp()
-    assert lib.sm_plan_create(0, w, h, d, sw, 1 if mode == "ghost" else 0, pairs, C.byref(plan)) == 0
+    opts = struct_from_spec(envs)          # (variants are chosen through sm_plan_create_ex, not the environment)
+    assert lib.sm_plan_create_ex(0, w, h, d, sw, 1 if mode == "ghost" else 0, pairs, C.byref(opts), C.byref(plan)) == 0
     assert lib.sm_find_edges(plan, L.data_ptr(), R.data_ptr(), 0.15, pairs, None, None, None) == 0
     libs[name_] = (lib, plan, dict(envs))
     if os.environ.get("AB_DESCRIBE"):
         lib.sm_plan_describe.restype = C.c_char_p
         lib.sm_plan_describe.argtypes = [vp]
         print(f"# {name_}: {lib.sm_plan_describe(plan).decode()}")
-    for k in envs:
-        os.environ.pop(k)
 torch.cuda.synchronize()
 
 ref = None
@@ -65,7 +64,6 @@ for r in range(rounds + 1):
     if r % 2 == 0:
         order.reverse()
     for name, (lib, plan, envs_) in order:
-        os.environ.update(envs_)           # some overrides are read at launch time
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
@@ -83,8 +81,6 @@ for r in range(rounds + 1):
         if os.environ.get("AB_EDGES"):
             assert lib.sm_match_wta(plan, pairs, web.data_ptr(), None, None) == 0
             torch.cuda.synchronize()
-        for k_ in envs_:
-            os.environ.pop(k_)
         if ref is None:
             ref = web.clone()
         else:

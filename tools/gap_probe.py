@@ -26,7 +26,7 @@ else:
     L = torch.from_numpy(left).cuda().repeat(P, 1, 1).contiguous()
     R = torch.from_numpy(right).cuda().repeat(P, 1, 1).contiguous()
 web = torch.empty((P, h, w), dtype=torch.int32, device="cuda")
-plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=P)
+plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=P, options=__import__('tools._options', fromlist=['from_env']).from_env() or None)
 print(plan.describe())
 s = torch.cuda.Stream()
 N = 200

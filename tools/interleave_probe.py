@@ -21,7 +21,7 @@ R = torch.from_numpy(right).cuda().repeat(P, 1, 1).contiguous()
 web = torch.empty((P, h, w), dtype=torch.int32, device="cuda")
 junk = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
 small = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
-plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=P)
+plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=P, options=__import__('tools._options', fromlist=['from_env']).from_env() or None)
 print(plan.describe())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 vp = C.c_void_p

@@ -3,7 +3,7 @@
 
     python3 tools/one_launch.py C3 1 [--best] [--launches 3] [--meta out.json]
 
-Tile height etc. follow the plan (SM_TILE_H / SM_DS in the environment override,
+Tile height etc. follow the plan (SM_TILE_H / SM_DS in this tool's environment override,
 as for every plan).  Writes the plan geometry + the model's variant key to --meta.
 """
 import argparse
@@ -29,7 +29,8 @@ ap.add_argument("--meta")
 a = ap.parse_args()
 
 w, h, d, sw, mode = CONFIGS[a.config]
-plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=a.pairs)
+from tools._options import from_env  # noqa: E402
+plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=a.pairs, options=from_env() or None)
 ls, rs = zip(*[make_pair(w, h, d, seed=j) for j in range(a.pairs)])
 left = torch.from_numpy(np.stack(ls)).cuda()
 right = torch.from_numpy(np.stack(rs)).cuda()

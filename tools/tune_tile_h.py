@@ -18,11 +18,11 @@ from stereomatching_amd.synth import CONFIGS, make_pair  # noqa: E402
 
 def time_plan(cfg, th, pairs=1, iters=20):
     w, h, d, sw, mode = CONFIGS[cfg]
+    from tools._options import from_env
+    opts = from_env()
     if th:
-        os.environ["SM_TILE_H"] = str(th)
-    else:
-        os.environ.pop("SM_TILE_H", None)
-    plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
+        opts["tile_h"] = th
+    plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs, options=opts or None)
     left, right = make_pair(w, h, d, seed=1)
     L = torch.from_numpy(left).cuda().repeat(pairs, 1, 1).contiguous()
     R = torch.from_numpy(right).cuda().repeat(pairs, 1, 1).contiguous()

@@ -29,7 +29,7 @@ from stereomatching_amd.synth import CONFIGS, make_pair  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 w, h, d, sw, mode = CONFIGS[cfg]
-plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
+plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs, options=__import__('tools._options', fromlist=['from_env']).from_env() or None)
 g = plan.geometry()
 print(plan.describe())
 ls, rs = zip(*[make_pair(w, h, d, seed=j) for j in range(pairs)])
