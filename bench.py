@@ -31,6 +31,10 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 throughput bar, NOT traffic: the fused kernel never moves it).
   cpu_baseline  the oracle's structure-faithful C port timed on this host's
                 cores on a bounded band of the same workload (rank 0, N = 1)
+  sad, ssd      (N = 1) the SAD / SSD cost mode -- the cost BASELINE.json's wording names, which
+                the reference does not implement: PARITY UNPINNED, the build's own definition --
+                at C3 (SAD 9x9) and C5 (SSD 11x11, ghost): ms per launch, Mpixel-disparities/s and
+                the VALU issue fraction.  Never part of `value`.
 """
 from __future__ import annotations
 
@@ -65,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--threshold", type=float, default=0.15)
     ap.add_argument("--with-best", action="store_true", help="also write score_best")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resident", type=int, default=4,
+                    help="batches of input pairs resident in HBM; the steps rotate over them")
+    ap.add_argument("--no-cost-modes", action="store_true", help="skip the extra `sad` / `ssd` objects (N = 1)")
     ap.add_argument("--cpu-rows", type=int, default=192, help="rows of the CPU-baseline band")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the edge kernel of step i+1 with the match kernel of step i "
@@ -177,6 +184,66 @@ def cpu_baseline(w, d, sw, mode, rows, threshold):
     return out
 
 
+def cost_modes(dev):
+    """The extra `sad` / `ssd` objects: the SAD / SSD cost mode (sm_cost_wta) at the two BASELINE
+    configurations that word their cost that way.  PARITY UNPINNED -- the reference implements the
+    edge-equality cost and nothing else -- so these are reported beside the
+    headline, never in it."""
+    import numpy as np
+    import torch
+    from stereomatching_amd import pipeline
+    from stereomatching_amd.synth import CONFIGS, make_pair
+
+    counts = {}
+    cfile = ROOT / "profiles" / "cost_valu.json"
+    if cfile.exists():
+        counts = json.loads(cfile.read_text())
+    res = {}
+    for key, cfg, cost in (("sad", "C3", "sad"), ("ssd", "C5", "ssd")):
+        w, h, d, sw, mode = CONFIGS[cfg]
+        plan = pipeline.StereoPlan(w, h, d, sw, mode, device=dev.index)
+        ls, rs = zip(*[make_pair(w, h, d, seed=500 + j) for j in range(2)])
+        L = torch.from_numpy(np.stack(ls)).to(dev)
+        R = torch.from_numpy(np.stack(rs)).to(dev)
+        web = torch.empty((1, h, w), dtype=torch.int32, device=dev)
+        t_end = time.perf_counter() + 0.025
+        n = 0
+        while n < 5 or time.perf_counter() < t_end:
+            plan.cost_wta(L[n % 2], R[n % 2], cost, want_best=False, web=web)
+            n += 1
+        torch.cuda.synchronize(dev)
+        launches = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(launches):
+            plan.cost_wta(L[i % 2], R[i % 2], cost, want_best=False, web=web)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / launches
+        o = {
+            "workload": f"{cfg}: {w}x{h} pair, {d} shifts, {sw}x{sw} {cost.upper()} window cost, {mode} border; "
+                        "uint8 gray in, int32 web out",
+            "parity": "UNPINNED: no reference implementation exists (SURVEY.md 0, 8f4); checked against the "
+                      "build's own CPU definition only",
+            "ms_per_launch": round(ms, 4),
+            "value": round(float(w) * h * d / ms / 1e3, 1),
+            "unit": "Mpixel-disparities/s",
+            "launches_timed": launches,
+            "timing": "HIP events on the launch stream around 20 back-to-back launches",
+        }
+        c = counts.get(f"{cfg}:{cost}")
+        if c:
+            ach = c["valu_wave_instructions"] / (ms * 1e-3) / 1e9
+            o["roofline"] = {"bound": "valu", "kernel": c.get("kernel"), "achieved": round(ach, 1),
+                             "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s", "frac": round(ach / VALU_PEAK_GIPS, 4),
+                             "valu_wave_instructions_per_launch": c["valu_wave_instructions"],
+                             "lane_instructions_per_pixel_shift": round(c["valu_wave_instructions"] * 64.0 / (float(w) * h * d), 2),
+                             "source": c.get("source")}
+        res[key] = o
+        plan.close()
+    return res
+
+
 def timing_stride(steps: int) -> int:
     """Bracket every `stride`-th match launch with HIP events: an event record costs
     ~4 us on the launch stream (tools/gap_probe.py), so long runs sample every 8th
@@ -282,22 +349,29 @@ def main():
     plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs, device=local_rank)
 
     import numpy as np
+    # `resident` different batches of pairs live in HBM and the steps rotate over them (and over as
+    # many result maps): no step reads the inputs or overwrites the map of the step before it.
+    # (All of it still fits the 256 MB Infinity Cache at 4K; the path is VALU-bound, 5 % of HBM.)
+    resident = max(1, args.resident)
     lefts, rights = [], []
-    for j in range(pairs):
+    for j in range(pairs * resident):
         a, b = make_pair(w, h, d, seed=1000 * rank + j)
         lefts.append(a)
         rights.append(b)
     left = torch.from_numpy(np.stack(lefts)).to(dev)
     right = torch.from_numpy(np.stack(rights)).to(dev)
-    web = torch.empty((pairs, h, w), dtype=torch.int32, device=dev)
+    web = torch.empty((pairs * resident, h, w), dtype=torch.int32, device=dev)
     best = torch.empty_like(web) if args.with_best else None
 
     import ctypes as C
     lib, check = pipeline.capi.lib, pipeline.capi.check
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    p_l, p_r = C.c_void_p(left.data_ptr()), C.c_void_p(right.data_ptr())
-    p_web = C.c_void_p(web.data_ptr())
-    p_best = C.c_void_p(best.data_ptr()) if best is not None else C.c_void_p(0)
+    img, mp = pairs * w * h, pairs * w * h * 4
+    p_l = [C.c_void_p(left.data_ptr() + k * img) for k in range(resident)]
+    p_r = [C.c_void_p(right.data_ptr() + k * img) for k in range(resident)]
+    p_web = [C.c_void_p(web.data_ptr() + k * mp) for k in range(resident)]
+    p_best = [C.c_void_p(best.data_ptr() + k * mp) if best is not None else C.c_void_p(0) for k in range(resident)]
+    turn = [0]
 
     # Optional: the inputs are resident and complete, so consecutive steps may overlap
     # (edge kernel of step i+1 beside the match kernel of step i on the plan's internal
@@ -306,7 +380,9 @@ def main():
     plan.prepare_threshold(args.threshold)     # set-up next to the allocations
 
     def step():
-        check(lib.sm_run(plan._h, p_l, p_r, args.threshold, pairs, p_web, p_best, stream))
+        k = turn[0]
+        turn[0] = k + 1 if k + 1 < resident else 0
+        check(lib.sm_run(plan._h, p_l[k], p_r[k], args.threshold, pairs, p_web[k], p_best[k], stream))
 
     # W warm-up steps as asked; a 4K step is ~0.1 ms, so W = 5 is over before the chip has
     # left its idle clocks (the same kernel measures ~10 % slower in the first millisecond
@@ -358,7 +434,7 @@ def main():
         torch.cuda.synchronize(dev)
         shard.barrier()
         g0 = time.perf_counter()
-        shard.gather_maps(web.cpu() if rehearsal else web, pairs * world, rank, world)
+        shard.gather_maps(web[:pairs].cpu() if rehearsal else web[:pairs], pairs * world, rank, world)
         torch.cuda.synchronize(dev)
         gather_ms = shard.max_over_ranks(time.perf_counter() - g0, red_dev) * 1e3
 
@@ -395,6 +471,10 @@ def main():
         "traffic_source": traffic_src,
         "kernel_ms": round(kernel_ms, 4),
         "kernel_launches_timed": n_timed,
+        "kernel_ms_method": ("start / end time stamps of the dispatch itself (hipExtLaunchKernel events: the "
+                             "clock rocprofv3's kernel trace reads), on the launch stream"
+                             if "bit-sliced" in plan.describe() else
+                             "HIP event records around the launch, on the launch stream"),
     }
     if model:
         ach = model["wave_instructions"] / kernel_s / 1e9
@@ -420,6 +500,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "warmup_effective": warm_steps,
         "warmup_steps_run": warm_steps,
         "warmup_note": f"{args.warmup} steps asked; untimed warm-up continued to {WARMUP_FLOOR_S * 1e3:.0f} ms "
                        f"and ends with {WARMUP_BURST} steps right in front of the timed region, so that "
@@ -430,6 +511,9 @@ def main():
         "vs_baseline": None,
         "dtype": "u32 bit-packed edges, i32 counts",
         "data": "synthetic",
+        "inputs": f"{resident} different resident batches of {pairs} pair(s), the steps rotate over them and over "
+                  f"{resident} result maps (all Infinity-Cache resident: "
+                  f"{(2 * img + mp) * resident / 1e6:.0f} MB)",
         "config": {
             "workload": f"{args.config}: {w}x{h} pair, {d} shifts, {sw}x{sw} window, {mode} border, "
                         f"{pairs} pair(s)/GPU/step; edges + fused match/aggregate/WTA -> web",
@@ -445,6 +529,10 @@ def main():
         out["gather_ms"] = round(gather_ms, 3)
     if e2e is not None:
         out["e2e"] = e2e
+    if world == 1 and not args.no_cost_modes and not rehearsal:
+        plan.close()
+        del left, right, web
+        out.update(cost_modes(dev))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, d, sw, mode, args.cpu_rows, args.threshold)
     emit(json.dumps(out))

@@ -181,14 +181,16 @@ class StereoPlan:
                                WEB_TYPES[web_dtype], _ptr(best if want_best else None), self._stream()))
         return web, (best if want_best else None)
 
-    def cost_wta(self, left, right, cost="sad", want_best=True):
+    def cost_wta(self, left, right, cost="sad", want_best=True, web=None, best=None):
         """SAD / SSD cost mode on the uint8 images (parity unpinned: the reference has no
         such mode) -> (web, best): arg-min over the shifts, first shift wins."""
         left = self._images(left, torch.uint8, "left")
         right = self._images(right, torch.uint8, "right")
         pairs = left.shape[0]
-        web = self._new(pairs, torch.int32)
-        best = self._new(pairs, torch.int32) if want_best else None
+        if web is None:
+            web = self._new(pairs, torch.int32)
+        if best is None and want_best:
+            best = self._new(pairs, torch.int32)
         check(lib.sm_cost_wta(self._h, _ptr(left), _ptr(right), {"sad": 1, "ssd": 2}[cost], pairs,
                               _ptr(web), _ptr(best), self._stream()))
         return web, best
