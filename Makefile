@@ -28,7 +28,11 @@ HOSTDIR := stereomatching_amd/host
 CSRC    := stereomatching_amd/csrc
 KERNELS := sm_match_bs_ds8 sm_match_bs sm_match_bs_duo8 sm_match_bs_duo sm_api sm_match sm_cost sm_cost_qs
 DEVOBJ  := $(addprefix stereomatching_amd/obj/product/,$(addsuffix .o,$(KERNELS)))
-HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-result -Iinclude -I$(CSRC)
+# (the same flags, in the same order, as HIPCC_FLAGS of stereomatching_amd/build.py: the two share
+#  stereomatching_amd/obj/product and its flags.txt stamp, so neither rebuilds what the other built)
+HIPFLAGS_BARE := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-result
+HIPFLAGS := $(HIPFLAGS_BARE) -Iinclude -I$(CSRC)
+DEVSTAMP := stereomatching_amd/obj/product/flags.txt
 DEVLIB  := stereomatching_amd/libstereo_hip.so
 LINKDEV := -Lstereomatching_amd -lstereo_hip -Wl,-rpath,'$$ORIGIN/../stereomatching_amd'
 
@@ -42,8 +46,13 @@ $(O):
 	mkdir -p $@
 
 # (the bit-sliced kernel's builds are four translation units: `make -j4` compiles them side by side)
-stereomatching_amd/obj/product/%.o: $(CSRC)/%.hip $(CSRC)/sm_internal.h $(CSRC)/sm_match_bs_kernel.h $(CSRC)/sm_cost.h include/stereo_hip.h
+# objects of another flag set are not reused: the stamp changes (and with it every object) only
+# when the flags do
+$(DEVSTAMP): FORCE
 	@mkdir -p $(dir $@)
+	@if [ "$$(cat $@ 2>/dev/null)" != "$(HIPFLAGS_BARE)" ]; then rm -f $(dir $@)*.o; echo "$(HIPFLAGS_BARE)" > $@; fi
+FORCE:
+stereomatching_amd/obj/product/%.o: $(CSRC)/%.hip $(CSRC)/sm_internal.h $(CSRC)/sm_match_bs_kernel.h $(CSRC)/sm_cost.h include/stereo_hip.h $(DEVSTAMP)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(DEVLIB): $(DEVOBJ)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
@@ -63,10 +72,10 @@ $(GPU_PROGRAMS): $(HOSTDIR)/stereopar.c $(O)/image.o $(O)/image_gpu.o $(DEVLIB)
 	$(CC) $(CFLAGS) $(if $(findstring ghost,$@),-DGHOST) $(filter %.c %.o,$^) -o $@ $(LINKDEV) -lm
 
 # a batch of pairs over all visible GPUs (not in the reference: its programs do one pair)
-$(BATCH_PROGRAM): $(HOSTDIR)/stereopar_batch.c $(O)/image.o $(DEVLIB)
+$(BATCH_PROGRAM): $(HOSTDIR)/stereopar_batch.c $(HOSTDIR)/batch_index.h $(O)/image.o $(DEVLIB)
 	$(CC) $(CFLAGS) $(filter %.c %.o,$^) -o $@ $(LINKDEV) -lm -lpthread
 
 clean:
 	rm -rf debug timing release *.ppm
 
-.PHONY: all clean
+.PHONY: all clean FORCE

@@ -60,11 +60,15 @@ def _compile_and_link(out: Path, objdir: Path, flags=(), verbose: bool = False, 
     objdir.mkdir(parents=True, exist_ok=True)
     common = [*HIPCC_FLAGS, *flags, f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 
-    stamp = objdir / "flags.txt"          # objects of another flag set are not reused
-    if not stamp.exists() or stamp.read_text() != " ".join(common):
+    # objects of another flag set are not reused.  The stamp holds the flags WITHOUT the include
+    # paths (they depend on where the tree is checked out; the Makefile spells them relatively and
+    # shares obj/product with this function, writing the same stamp), and is never tracked.
+    stamp = objdir / "flags.txt"
+    text = " ".join([*HIPCC_FLAGS, *flags])
+    if not stamp.exists() or stamp.read_text().strip() != text:
         for old in objdir.glob("*.o"):
             old.unlink()
-        stamp.write_text(" ".join(common))
+        stamp.write_text(text + "\n")
 
     def one(src: str) -> Path:
         obj = objdir / (Path(src).stem + ".o")

@@ -147,7 +147,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_map4(i32 *p, v4i v)
 {
 #if SM_BS_STORE == 1
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    // (the s_nop belongs to the statement: the compiler does not see a store of more than 8 bytes
+    // here, so nothing else keeps a VALU write of the data registers one wait state away from it)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 #elif SM_BS_STORE == 2
     *reinterpret_cast<v4i *>(p) = v;
 #else

@@ -300,8 +300,14 @@ static int decode_png(const uint8_t *buf, size_t len, uint8_t **pixels, int *w, 
         free(z);
         return 1;
     }
+    /* dimensions as stb_image bounds them (1 << 24 per side), and nothing is allocated for a
+     * header that promises more pixels than its compressed stream can hold: deflate expands at
+     * most 1032 : 1 (a 258-byte match per 2 bits), so a file of zlen bytes with larger
+     * dimensions is corrupt whatever follows                                                 */
+    if (*w > (1 << 24) || *h > (1 << 24)) { free(z); return 1; }
     const size_t row_bytes = ((size_t)*w * depth + 7) / 8;
     const size_t raw_len = (row_bytes + 1) * (size_t)*h;
+    if (raw_len / 1032 > zlen) { free(z); return 1; }
     uint8_t *raw = malloc(raw_len);
     if (!raw) { free(z); return 1; }
     Inflate s = {z + 2, zlen - 2, 0, 0, 0, raw, raw_len, 0}; /* skip the 2-byte zlib header */

@@ -29,6 +29,8 @@
  *     -o DIR        write each web map to DIR/web-<index>.pgm (binary PGM, maxval =
  *                   shifts; DIR must exist).  Default: no files (timing).
  *     -r REPEAT     process the list REPEAT times (throughput measurements)
+ *     -x N          test hook: every device reports a failure when it is about to submit its
+ *                   N-th batch (exercises the error path of the two host threads per device)
  *
  * stdout: one line
  *   pairs = P, devices = K, width = W, height = H, shifts = D, elapsed = T, pairs_per_s = R, checksum = C
@@ -39,8 +41,10 @@
  */
 #include "image.h"
 #include "stereo_hip.h"
+#include "batch_index.h"
 
 #include <pthread.h>
+#include <stdatomic.h>
 #include <semaphore.h>
 #ifdef __SSE2__
 #include <emmintrin.h>
@@ -75,14 +79,23 @@ typedef struct {
     /* result */
     unsigned long long checksum;
     int done_pairs;
-    volatile int failed;      /* set by either of the device's two host threads, read by both */
-    char error[512];
+    atomic_int failed;        /* set by either of the device's two host threads, read by both */
+    char error[512];          /* written by the thread that sets `failed` first (error_claimed) */
+    atomic_int error_claimed;
+    int fail_at;              /* -x: inject a failure at this batch (0 = never) */
     /* the device's two host threads: the submitter (worker_main) queues batches into SLOTS
      * buffer sets; the collector (collector_main) waits for each download, sums and writes the
      * maps and hands the set back -- reading 2 MB per map takes the host longer than the GPU
      * and the link need for it, so it must not sit between two submissions */
     sem_t slot_free, slot_filled;
-    int in_flight[SLOTS], first_index[SLOTS];     /* pairs in the set (0: the end), first pair's index */
+    /* A set's in_flight / first_index are written by the submitter BEFORE it posts slot_filled for
+     * that set and read by the collector AFTER it has waited for it (and the other way round with
+     * slot_free): the semaphores order them.  The end is signalled separately -- `submitted` =
+     * batches handed over so far, `finished` = no more will come -- never by rewriting the fields
+     * of a set the collector may be looking at. */
+    int in_flight[SLOTS], first_index[SLOTS];     /* pairs in the set, first pair's index */
+    atomic_long submitted;
+    atomic_int finished;
     void *ev_down[SLOTS], *h_web[SLOTS];
     int mine, web_bytes;
 } Worker;
@@ -114,11 +127,18 @@ static int fail(const char *message)
     return 1;
 }
 
+/* the first thread to report a failure owns the message */
+static void set_failed(Worker *w, const char *message)
+{
+    if (atomic_exchange(&w->error_claimed, 1) == 0)
+        snprintf(w->error, sizeof w->error, "%s", message);
+    atomic_store(&w->failed, 1);
+}
+
 #define W_TRY(call)                                                        \
     do {                                                                   \
         if ((call) != SM_OK) {                                             \
-            snprintf(w->error, sizeof w->error, "%s", sm_last_error());    \
-            w->failed = 1;                                                 \
+            set_failed(w, sm_last_error());                                \
             goto out;                                                      \
         }                                                                  \
     } while (0)
@@ -191,16 +211,16 @@ static void *collector_main(void *arg)
 {
     Worker *w = arg;
     const size_t n = (size_t)w->width * w->height;
-    for (int s = 0;; s = (s + 1) % SLOTS) {
+    long processed = 0;
+    for (int s = 0;; s = (s + 1) % SLOTS, processed++) {
         sem_wait(&w->slot_filled);
+        /* one post per submitted batch, and one more when the submitter is done or has failed */
+        if (atomic_load(&w->failed) || processed == atomic_load(&w->submitted))
+            break;
         const int b = w->in_flight[s];
-        if (b == 0)
-            break;                          /* the submitter's end marker */
-        if (!w->failed && sm_event_sync(w->device, w->ev_down[s]) != SM_OK) {
-            snprintf(w->error, sizeof w->error, "%s", sm_last_error());
-            w->failed = 1;
-        }
-        for (int k = 0; k < b && !w->failed; k++) {
+        if (sm_event_sync(w->device, w->ev_down[s]) != SM_OK)
+            set_failed(w, sm_last_error());
+        for (int k = 0; k < b && !atomic_load(&w->failed); k++) {
             const uint8_t *m8 = (const uint8_t *)w->h_web[s] + (size_t)k * n * w->web_bytes;
             unsigned long long sum = 0;
             if (w->web_bytes == 1) {
@@ -211,7 +231,7 @@ static void *collector_main(void *arg)
             }
             w->checksum += sum;
             const long seq = w->first_index[s] + k;                         /* in this device's sequence */
-            const int j = w->rank + (int)(seq % w->mine) * w->n_devices;    /* global pair index */
+            const int j = batch_global_index(w->rank, seq, w->mine, w->n_devices);   /* line of the pair list */
             if (w->out_dir && seq < w->mine)
                 write_pgm(w->out_dir, j, m8, w->web_bytes, w->width, w->height, w->num_shifts);
             w->done_pairs++;
@@ -239,8 +259,7 @@ static void *worker_main(void *arg)
     int collector_started = 0;
 
     /* this device's pairs: j with j mod n_devices == rank, over all repeats */
-    int mine = 0;
-    for (int j = w->rank; j < w->n_pairs; j += w->n_devices) mine++;
+    const int mine = batch_pairs_of_rank(w->n_pairs, w->rank, w->n_devices);
     const long total = (long)mine * w->repeat;
     w->mine = mine;
     w->web_bytes = web_bytes;
@@ -251,23 +270,19 @@ static void *worker_main(void *arg)
     if (sm_plan_create(dev, w->width, w->height, w->num_shifts, w->square_width, w->border,
                        w->batch, &plan) ||
         sm_plan_prepare_threshold(plan, w->threshold, NULL) ||
-        sm_stream_create(dev, &st_up) || sm_stream_create(dev, &st_run) || sm_stream_create(dev, &st_down)) {
-        snprintf(w->error, sizeof w->error, "%s", sm_last_error());
-        w->failed = 1;
-    }
-    for (int s = 0; s < SLOTS && !w->failed; s++) {
+        sm_stream_create(dev, &st_up) || sm_stream_create(dev, &st_run) || sm_stream_create(dev, &st_down))
+        set_failed(w, sm_last_error());
+    for (int s = 0; s < SLOTS && !atomic_load(&w->failed); s++) {
         if (sm_event_create(dev, &ev_up[s]) || sm_event_create(dev, &ev_ran[s]) ||
             sm_event_create(dev, &w->ev_down[s]) ||
             sm_host_alloc(n * web_bytes * w->batch, &w->h_web[s]) ||
             sm_malloc(dev, 2 * n * w->batch, (void **)&d_in[s]) ||
-            sm_malloc(dev, n * web_bytes * w->batch, &d_web[s])) {
-            snprintf(w->error, sizeof w->error, "%s", sm_last_error());
-            w->failed = 1;
-        }
+            sm_malloc(dev, n * web_bytes * w->batch, &d_web[s]))
+            set_failed(w, sm_last_error());
     }
     /* one pair through every stream before the clock starts: the first transfer and the first
      * launch on a stream set up DMA queues and load code objects (tens of milliseconds) */
-    if (!w->failed && mine > 0) {
+    if (!atomic_load(&w->failed) && mine > 0) {
         const int j = w->rank;
         if (sm_memcpy_h2d_async(dev, d_in[0], w->pairs[j].px[0], n, st_up) ||
             sm_memcpy_h2d_async(dev, d_in[0] + n, w->pairs[j].px[1], n, st_up) ||
@@ -275,24 +290,26 @@ static void *worker_main(void *arg)
             sm_run_typed(plan, d_in[0], d_in[0] + n, w->threshold, 1, d_web[0], web_type, NULL, st_run) ||
             sm_stream_sync(dev, st_run) ||
             sm_memcpy_d2h_async(dev, w->h_web[0], d_web[0], n * web_bytes, st_down) ||
-            sm_stream_sync(dev, st_down)) {
-            snprintf(w->error, sizeof w->error, "%s", sm_last_error());
-            w->failed = 1;
-        }
+            sm_stream_sync(dev, st_down))
+            set_failed(w, sm_last_error());
     }
-    if (!w->failed && pthread_create(&collector, NULL, collector_main, w) == 0)
-        collector_started = 1;
-    else if (!w->failed) {
-        snprintf(w->error, sizeof w->error, "error: cannot start the collector thread");
-        w->failed = 1;
+    if (!atomic_load(&w->failed)) {
+        if (pthread_create(&collector, NULL, collector_main, w) == 0)
+            collector_started = 1;
+        else
+            set_failed(w, "error: cannot start the collector thread");
     }
     pthread_barrier_wait(w->start);       /* main() takes t1 here */
-    if (w->failed)
+    if (atomic_load(&w->failed))
         goto out;
 
-    long next = 0;            /* index into this device's sequence of pairs */
-    for (int s = 0; next < total && !w->failed; s = (s + 1) % SLOTS) {
+    long next = 0, batches = 0;           /* index into this device's sequence of pairs; batches submitted */
+    for (int s = 0; next < total && !atomic_load(&w->failed); s = (s + 1) % SLOTS) {
         sem_wait(&w->slot_free);          /* the collector is done with this set's previous maps */
+        if (w->fail_at && batches + 1 == w->fail_at) {
+            set_failed(w, "error: injected failure (-x)");
+            goto out;
+        }
         /* upload the next batch straight from the pinned arena the images were decoded
          * into: lefts then rights, as sm_run expects a batch (no staging copy on the host).
          * The set's input buffer is free once the kernels that last read it have run,
@@ -301,7 +318,7 @@ static void *worker_main(void *arg)
         while (b < w->batch && next + b < total) b++;
         if (used[s]) W_TRY(sm_stream_wait_event(dev, st_up, ev_ran[s]));
         for (int k = 0; k < b; k++) {
-            const int j = w->rank + (int)((next + k) % mine) * w->n_devices;
+            const int j = batch_global_index(w->rank, next + k, mine, w->n_devices);
             W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)k * n, w->pairs[j].px[0], n, st_up));
             W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)(b + k) * n, w->pairs[j].px[1], n, st_up));
         }
@@ -318,22 +335,15 @@ static void *worker_main(void *arg)
         w->first_index[s] = (int)next;
         w->in_flight[s] = b;
         next += b;
+        atomic_store(&w->submitted, ++batches);
         sem_post(&w->slot_filled);
     }
 out:
     if (collector_started) {
-        /* end marker in the next set the collector will look at: it takes them in submission
-         * order, so that is the one after the last batch (wait until it is free) */
-        if (!w->failed) {
-            long batches = (total + w->batch - 1) / w->batch;
-            sem_wait(&w->slot_free);
-            w->in_flight[batches % SLOTS] = 0;
-            sem_post(&w->slot_filled);
-        } else {
-            /* an error: the collector skips the work of whatever is queued; mark every set */
-            for (int k = 0; k < SLOTS; k++) w->in_flight[k] = 0;
-            sem_post(&w->slot_filled);
-        }
+        /* the end, successful or not: one more post.  The collector takes the batches in
+         * submission order and stops when it has seen `submitted` of them (or a failure). */
+        atomic_store(&w->finished, 1);
+        sem_post(&w->slot_filled);
         pthread_join(collector, NULL);
     }
     if (st_up) sm_stream_sync(dev, st_up);
@@ -375,7 +385,7 @@ static int parse_devices(const char *list, int *devices, int visible)
 int main(int argc, char *argv[])
 {
     const char *device_list = getenv("STEREO_DEVICES"), *out_dir = NULL;
-    int num_shifts = NUM_SHIFTS, border = SM_TOROIDAL, batch = 8, repeat = 1;
+    int num_shifts = NUM_SHIFTS, border = SM_TOROIDAL, batch = 8, repeat = 1, fail_at = 0;
     const char *env = getenv("STEREO_NUM_SHIFTS");
     if (env && atoi(env) > 0)
         num_shifts = atoi(env);
@@ -384,7 +394,7 @@ int main(int argc, char *argv[])
     for (; a < argc && argv[a][0] == '-' && argv[a][1]; a++) {
         const char opt = argv[a][1];
         if (opt == 'g') { border = SM_GHOST; continue; }
-        if (a + 1 >= argc || !strchr("dnbor", opt)) { a = argc; break; }
+        if (a + 1 >= argc || !strchr("dnborx", opt)) { a = argc; break; }
         const char *val = argv[++a];
         if (opt == 'd') device_list = val;
         else if (opt == 'o') out_dir = val;
@@ -397,6 +407,7 @@ int main(int argc, char *argv[])
             if (opt == 'n') num_shifts = v;
             if (opt == 'b') batch = v;
             if (opt == 'r') repeat = v;
+            if (opt == 'x') fail_at = v;
         }
     }
     if (a >= argc) {
@@ -503,7 +514,9 @@ int main(int argc, char *argv[])
         w->pairs = pairs; w->n_pairs = n_pairs; w->repeat = repeat;
         w->width = width; w->height = height; w->num_shifts = num_shifts;
         w->square_width = square_width; w->border = border; w->batch = batch;
-        w->threshold = threshold; w->out_dir = out_dir; w->start = &start;
+        w->threshold = threshold; w->out_dir = out_dir; w->start = &start; w->fail_at = fail_at;
+        /* (returning from main ends the process, and with it the device threads already waiting
+         * at the start barrier) */
         if (pthread_create(&threads[k], NULL, worker_main, w))
             return fail("error: cannot start a device thread");
     }
@@ -513,7 +526,7 @@ int main(int argc, char *argv[])
     int done = 0, failed = 0;
     for (int k = 0; k < n_devices; k++) {
         pthread_join(threads[k], NULL);
-        if (workers[k].failed) {
+        if (atomic_load(&workers[k].failed)) {
             fprintf(stderr, "%s\n", workers[k].error);
             failed = 1;
         }

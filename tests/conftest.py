@@ -21,7 +21,29 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz"))
+    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz") if not p.stem.endswith("_pair"))
+
+
+def big_reference_cases():
+    """(pair name, mode) of tests/golden/ref_big_digests.json: the reference's own large test pairs
+    (pixels in <name>_pair.npz) with SHA-256 digests of what the compiled reference made of them"""
+    import json
+    f = GOLDEN_DIR / "ref_big_digests.json"
+    if not f.exists():
+        return []
+    return sorted(tuple(k.split(":")) for k in json.loads(f.read_text()))
+
+
+def load_big_reference(name, mode):
+    import json
+    z = np.load(GOLDEN_DIR / f"{name}_pair.npz")
+    d = json.loads((GOLDEN_DIR / "ref_big_digests.json").read_text())[f"{name}:{mode}"]
+    return z["left"], z["right"], d
+
+
+def sha256_of(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
 def load_golden(name):

@@ -79,5 +79,42 @@ def main():
         print(name, {k: v.shape for k, v in keep.items() if k in ("left", "web-1")})
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--big" not in sys.argv:
     main()
+
+
+# ---------------------------------------------------------------------------
+# the reference's LARGE test pairs (test/time.sh:6-9 runs all of test/imgs): the decoded pixels
+# of a pair are stored once, and of the arrays the compiled reference produces for it at its
+# defaults only SHA-256 digests -- enough to pin the 4K tiling of the HIP path at D = 30 /
+# S = 21 to the reference itself, bit for bit, without shipping gigabytes.
+#     python tests/golden/make_golden.py --big       (minutes: the serial program at 4K)
+# ---------------------------------------------------------------------------
+BIG_PAIRS = {"ref_1920x1080": Path("/root/reference/test/imgs/4-1920x1080"),
+             "ref_3840x2160": Path("/root/reference/test/imgs/5-3840x2160")}
+BIG_KEYS = ("edges-1", "edges-2", "score_best-0", "web-1", "web-2", "output-0")
+
+
+def main_big():
+    import hashlib
+    import json
+    if not oracle.ref_available():
+        sys.exit("oracle/_ref is missing: run `make -C oracle ref` where /root/reference exists")
+    out_dir = Path(__file__).resolve().parent
+    digests = {}
+    for name, d in BIG_PAIRS.items():
+        left, right = decode_gray_png(d / "a.png"), decode_gray_png(d / "b.png")
+        np.savez_compressed(out_dir / f"{name}_pair.npz", left=left, right=right)
+        for mode in ("toroidal", "ghost"):
+            ref = oracle.run_reference(left, right, 0.15, 21, 32, 10, mode, keep=lambda k: k in BIG_KEYS)
+            digests[f"{name}:{mode}"] = {
+                "params": {"threshold": 0.15, "square_width": 21, "times": 32, "lines": 10, "num_shifts": 30},
+                "sha256": {k: hashlib.sha256(np.ascontiguousarray(ref[k]).tobytes()).hexdigest() for k in BIG_KEYS},
+                "dtype": {k: str(ref[k].dtype) for k in BIG_KEYS},
+                "shape": list(ref["web-1"].shape)}
+            print(name, mode, digests[f"{name}:{mode}"]["sha256"]["web-1"][:16], flush=True)
+            (out_dir / "ref_big_digests.json").write_text(json.dumps(digests, indent=1) + "\n")
+
+
+if __name__ == "__main__" and "--big" in sys.argv:
+    main_big()

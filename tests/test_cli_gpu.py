@@ -102,6 +102,57 @@ def test_stereopar_batch_matches_the_oracle(programs, tmp_path, ghost):  # noqa:
     assert int(fields["checksum"]) == 2 * total
 
 
+def test_stereopar_batch_two_workers_on_one_device(programs, tmp_path):  # noqa: F811
+    """`-d 0,0`: the multi-device split of stereopar-batch (pair j -> worker j mod n, a host thread
+    pair, a plan and three streams per worker) with BOTH workers on device 0 -- what a one-GPU box
+    can run of the n_devices > 1 path: every map equals the oracle's, in list order."""
+    import numpy as np
+    from tests import oracle
+    w, h, d, sw, n_pairs = 160, 96, 30, 9, 9
+    lines, pairs = [], []
+    for j in range(n_pairs):
+        left, right = make_pair(w, h, d, seed=300 + j)
+        write_pgm(tmp_path / f"l{j}.pgm", left)
+        write_pgm(tmp_path / f"r{j}.pgm", right)
+        lines.append(f"l{j}.pgm r{j}.pgm")
+        pairs.append((left, right))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    os.mkdir(tmp_path / "out")
+    exe = programs["timing"]["stereopar"].parent / "stereopar-batch"
+    p = subprocess.run([str(exe), "-d", "0,0", "-n", str(d), "-b", "2", "-o", "out", "list.txt", "0.15", str(sw)],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    fields = dict(f.split(" = ") for f in p.stdout.strip().split(", "))
+    assert int(fields["pairs"]) == n_pairs and int(fields["devices"]) == 2
+    total = 0
+    for j, (left, right) in enumerate(pairs):
+        el = oracle.find_all_edges(left, 0.15, "toroidal")
+        er = oracle.find_all_edges(right, 0.15, "toroidal")
+        _, web = oracle.hot_path(el, er, d, sw, "toroidal")
+        assert np.array_equal(read_pgm_any(tmp_path / "out" / f"web-{j}.pgm"), web), j
+        total += int(web.sum())
+    assert int(fields["checksum"]) == total
+
+
+def test_stereopar_batch_failure_path_ends_cleanly(programs, tmp_path):  # noqa: F811
+    """-x N injects a failure when a worker is about to submit its N-th batch, with batches in
+    flight: both host threads of every worker must stop, the message goes to stderr and the exit
+    code is 1 (the reference's convention) -- no hang, no result line."""
+    w, h, d = 96, 64, 16
+    lines = []
+    for j in range(6):
+        left, right = make_pair(w, h, d, seed=400 + j)
+        write_pgm(tmp_path / f"l{j}.pgm", left)
+        write_pgm(tmp_path / f"r{j}.pgm", right)
+        lines.append(f"l{j}.pgm r{j}.pgm")
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    exe = programs["timing"]["stereopar"].parent / "stereopar-batch"
+    for devices in ("0", "0,0"):
+        p = subprocess.run([str(exe), "-d", devices, "-n", str(d), "-b", "1", "-r", "50", "-x", "7",
+                            "list.txt", "0.15", "5"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 1 and "injected failure" in p.stderr and not p.stdout.strip(), (p.stdout, p.stderr)
+
+
 def read_pgm_any(path):
     """binary PGM with any maxval <= 255 (stereopar-batch writes maxval = number of shifts)"""
     import numpy as np

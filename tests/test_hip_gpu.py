@@ -7,7 +7,7 @@ import torch
 
 from stereomatching_amd.synth import CONFIGS, make_pair
 from tests import oracle
-from tests.conftest import golden_cases, load_golden
+from tests.conftest import big_reference_cases, golden_cases, load_big_reference, load_golden, sha256_of
 
 pytestmark = pytest.mark.gpu
 PLANE_SHIFTS = (0, 1, 7, 29)
@@ -56,6 +56,25 @@ def test_pipeline_matches_reference_golden(hip, name):
         assert np.array_equal(host(m), z[f"matches-{d}"]), (name, d)
         assert np.array_equal(host(sa), z[f"score_all-{d}"]), (name, d)
         assert np.array_equal(host(sc), z[f"scores-{d}"]), (name, d)
+    plan.close()
+
+
+@pytest.mark.parametrize("name,mode", big_reference_cases())
+def test_reference_large_test_pairs_hash_to_the_reference(hip, name, mode):
+    """The reference's own 1080p and 4K test pairs (test/imgs/4-1920x1080, 5-3840x2160; test/time.sh:6-9)
+    at its defaults (30 shifts, 21 x 21, 32 fill sweeps, 10 lines): every stage of the HIP pipeline
+    hashes to what the COMPILED REFERENCE produced -- the 4K tiling pinned to the reference itself,
+    not to the restatement."""
+    left, right, d = load_big_reference(name, mode)
+    p = d["params"]
+    h, w = left.shape
+    plan = hip.StereoPlan(w, h, p["num_shifts"], p["square_width"], mode)
+    res = plan.algorithm(dev(left), dev(right),
+                         hip.AlgorithmParams(p["threshold"], p["square_width"], p["times"], p["lines"]))
+    for k in ("edges-1", "edges-2", "score_best-0", "web-1", "web-2", "output-0"):
+        got = host(res[k])[0]
+        assert str(got.dtype) == d["dtype"][k] and list(got.shape) == d["shape"], (k, got.dtype, got.shape)
+        assert sha256_of(got) == d["sha256"][k], (name, mode, k, plan.describe())
     plan.close()
 
 

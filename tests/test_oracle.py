@@ -115,3 +115,22 @@ def test_fill_web_holes_and_contour_semantics():
         oracle.draw_contour_map(np.full((4, 4), 3, np.int32), 10)
     out = oracle.draw_contour_map(np.arange(1, 31, dtype=np.int32).reshape(5, 6), 10)
     assert out.dtype == np.uint8 and out.sum() > 0
+
+
+@pytest.mark.parametrize("name,mode", __import__("tests.conftest", fromlist=["x"]).big_reference_cases())
+def test_restatement_matches_the_reference_on_its_large_test_pairs(name, mode):
+    """test/imgs/4-1920x1080 and 5-3840x2160 (what test/time.sh:6-9 runs) at the reference's defaults:
+    every stage of the restatement hashes to what the compiled reference produced (digests made by
+    tests/golden/make_golden.py --big); the restatement is run on row bands in threads."""
+    from tests.conftest import load_big_reference, sha256_of
+    left, right, d = load_big_reference(name, mode)
+    p = d["params"]
+    el = oracle.find_all_edges_banded(left, p["threshold"], mode)
+    er = oracle.find_all_edges_banded(right, p["threshold"], mode)
+    assert sha256_of(el) == d["sha256"]["edges-1"] and sha256_of(er) == d["sha256"]["edges-2"]
+    best, web = oracle.hot_path_banded(el, er, p["num_shifts"], p["square_width"], mode)
+    assert sha256_of(best) == d["sha256"]["score_best-0"]
+    assert sha256_of(web) == d["sha256"]["web-1"]
+    web2 = oracle.fill_web_holes(web, p["times"])
+    assert sha256_of(web2) == d["sha256"]["web-2"]
+    assert sha256_of(oracle.draw_contour_map(web2, p["lines"])) == d["sha256"]["output-0"]

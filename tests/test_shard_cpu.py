@@ -81,6 +81,22 @@ def test_two_rank_gloo_shard_and_gather(tmp_path, total_pairs):
         assert np.array_equal(got[j], oracle.hot_path(le, re, 8, 3)[1]), j
 
 
+@pytest.mark.parametrize("total_pairs", [7, 2])
+def test_three_rank_gloo_gather_with_uneven_counts(tmp_path, total_pairs):
+    """gather_maps' send / receive pairs at world 3: 7 pairs = shares of 3, 2, 2; 2 pairs = shares of
+    1, 1, 0 (a rank with nothing to send takes no part in the transfer and still passes the barriers)"""
+    from tests import oracle
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), total_pairs, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "gathered.npy")
+    assert got.shape == (total_pairs, 12, 20)
+    for j in range(total_pairs):
+        rng = np.random.default_rng(j)
+        le = rng.integers(0, 2, (12, 20), dtype=np.uint8)
+        re = rng.integers(0, 2, (12, 20), dtype=np.uint8)
+        assert np.array_equal(got[j], oracle.hot_path(le, re, 8, 3)[1]), j
+
+
 def test_bench_refuses_a_world_size_mismatch():
     import subprocess
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
