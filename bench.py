@@ -444,7 +444,8 @@ def main():
 
     kernel_s = kernel_ms * 1e-3
     acv = A_CV_BYTES * units_per_step / kernel_s / 1e9             # GB/s (throughput bar)
-    compulsory = 4.0 * w * h * pairs + plan.workspace_bytes() / 2 / plan.max_pairs * pairs
+    geo = plan.geometry()
+    compulsory = 4.0 * w * h * pairs + 2 * 4.0 * geo["ext_words"] * geo["ext_rows"] * pairs     # web out + packed edge bits in
     amin_kernel = compulsory / kernel_s / 1e9
     amin_step = A_MIN_BYTES * w * h * pairs / (elapsed / args.steps) / 1e9
     # VALU wave-instructions of one launch: the plan's analytic model (per-wave set-up +

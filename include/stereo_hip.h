@@ -20,6 +20,11 @@
  *     owns only its private workspace.
  *   - launches are asynchronous on the given stream; nothing here
  *     synchronises except sm_stream_sync, sm_memcpy_* and sm_plan_status.
+ *   - a plan is a single-threaded, single-stream object: its workspace (the packed edge images,
+ *     the staging map of the narrow results of the fallback kernels, the timing events) is shared
+ *     by all calls on it, so calls on ONE plan must come from one thread at a time and their
+ *     launches must be ordered (one stream, or streams chained with events).  Concurrency comes
+ *     from several plans (stereopar-batch: one per device thread), not from sharing one.
  *   - images are row-major, W*H elements, no padding.  A batch of pairs is
  *     `pairs` consecutive images.  The ghost-border variant needs no padded
  *     arrays (src/ghost.h): the halo is synthesised inside the kernels.

@@ -872,6 +872,10 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_flags, 4 * sizeof(i32), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemset(p->d_ext, 0, p->ext_bytes);
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(i32));
+    // kernels without a narrow store path write narrow maps through an int32 staging map: part of
+    // the workspace, allocated here (a hipMalloc inside a launch call would synchronise the device)
+    if (e == hipSuccess && p->kernel != SM_KERNEL_BS)
+        e = hipMalloc((void **)&p->d_web_tmp, (size_t)max_pairs * width * height * sizeof(i32));
     if (e != hipSuccess) {
         for (int b = 0; b < 2; b++) {
             if (p->d_ext_buf[b]) (void)hipFree(p->d_ext_buf[b]);
@@ -882,6 +886,7 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
         if (p->ev_inputs) (void)hipEventDestroy(p->ev_inputs);
         if (p->d_flags) (void)hipFree(p->d_flags);
         if (p->d_edge_tab) (void)hipFree(p->d_edge_tab);
+        if (p->d_web_tmp) (void)hipFree(p->d_web_tmp);
         if (p->h_flags) (void)hipHostFree(p->h_flags);
         free(p);
         return sm_fail(e == hipErrorOutOfMemory ? SM_ERR_NOMEM : SM_ERR_HIP,
@@ -957,7 +962,9 @@ extern "C" int sm_plan_geometry(const sm_plan *plan, sm_geometry *out)
 
 extern "C" size_t sm_plan_workspace_bytes(const sm_plan *plan)
 {
-    return plan ? 2 * plan->ext_bytes + 4 * sizeof(i32) + 768 * sizeof(u32) : 0;
+    if (!plan) return 0;
+    const size_t staging = plan->d_web_tmp ? (size_t)plan->max_pairs * plan->width * plan->height * sizeof(i32) : 0;
+    return 2 * plan->ext_bytes + 4 * sizeof(i32) + 768 * sizeof(u32) + staging;
 }
 
 // synchronise `st` and return the plan's flags as they were at that point; flags in
@@ -1125,25 +1132,22 @@ extern "C" int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d
 extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int web_type,
                                   int32_t *d_best, void *stream)
 {
-    SM_TRY(check_plan_pairs(plan, pairs, "sm_match_wta"));
-    if (!d_web_any) return sm_fail(SM_ERR_ARG, "sm_match_wta: d_web is NULL");
+    const char *me = web_type == SM_WEB_I32 ? "sm_match_wta" : "sm_match_wta_typed";
+    SM_TRY(check_plan_pairs(plan, pairs, me));
+    if (!d_web_any) return sm_fail(SM_ERR_ARG, "%s: d_web is NULL", me);
     if (web_type != SM_WEB_I32 && web_type != SM_WEB_U16 && web_type != SM_WEB_U8)
-        return sm_fail(SM_ERR_ARG, "sm_match_wta: web_type %d is not SM_WEB_I32/U16/U8", web_type);
+        return sm_fail(SM_ERR_ARG, "%s: web_type %d is not SM_WEB_I32/U16/U8", me, web_type);
     if ((web_type == SM_WEB_U8 && plan->num_shifts > 255) || (web_type == SM_WEB_U16 && plan->num_shifts > 65535))
-        return sm_fail(SM_ERR_ARG, "sm_match_wta: %d shifts do not fit the requested web type", plan->num_shifts);
+        return sm_fail(SM_ERR_ARG, "%s: %d shifts do not fit the requested web type", me, plan->num_shifts);
     const int web_bytes = web_type == SM_WEB_I32 ? 4 : web_type == SM_WEB_U16 ? 2 : 1;
     int32_t *d_web = (int32_t *)d_web_any;
+    // kernels without a narrow store path: int32 into the plan's staging map (allocated with the
+    // plan), then narrow.  ONE staging map per plan: see the threading note in stereo_hip.h
     const bool via_tmp = web_bytes != 4 && plan->kernel != SM_KERNEL_BS;
-    if (via_tmp) {
-        // kernels without a narrow store path: int32 into a plan-owned map, then narrow
-        const size_t need = (size_t)plan->max_pairs * plan->width * plan->height * sizeof(i32);
-        SM_TRY(use_device(plan->device));
-        if (!plan->d_web_tmp) SM_HIP(hipMalloc((void **)&plan->d_web_tmp, need));
-        d_web = plan->d_web_tmp;
-    }
+    if (via_tmp) d_web = plan->d_web_tmp;
     if (pairs > plan->pairs_loaded)
-        return sm_fail(SM_ERR_ARG, "sm_match_wta: %d pairs requested but edges of only %d are loaded "
-                       "(call sm_find_edges or sm_load_edges first)", pairs, plan->pairs_loaded);
+        return sm_fail(SM_ERR_ARG, "%s: %d pairs requested but edges of only %d are loaded "
+                       "(call sm_find_edges or sm_load_edges first)", me, pairs, plan->pairs_loaded);
     SM_TRY(use_device(plan->device));
     // event records are not free (~4 us each on the launch stream): time a sample of
     // the launches, and record the buffer-release event only when someone can wait on it
@@ -1155,18 +1159,18 @@ extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int
     // is timed (bench.py at --steps 20).  Other kernels keep the bracketing records.
     const bool attach = timed && plan->kernel == SM_KERNEL_BS && !via_tmp && !plan->opt.timing_by_records;
     if (timed && !attach) SM_HIP(hipEventRecord(plan->t_begin[plan->timing_n], (hipStream_t)stream));
-    plan->launch_ev_begin = attach ? plan->t_begin[plan->timing_n] : nullptr;
-    plan->launch_ev_end = attach ? plan->t_end[plan->timing_n] : nullptr;
     {
-        // int4 stores need 16-byte aligned maps; otherwise this launch stores scalars
-        // (kernel arguments are copied at launch time)
-        const int vec_ok = plan->g.vec_ok;
+        // what this launch adds to the plan's geometry, by value (the plan itself is not touched):
+        // int4 stores need 16-byte aligned maps, otherwise this launch stores scalars; the element
+        // size of the web map; the events of a timed launch
+        MatchLaunch l;
+        l.g = plan->g;
         const int kb = via_tmp ? 4 : web_bytes;
-        if (((uintptr_t)d_web & (4 * kb - 1)) != 0 || ((uintptr_t)d_best & 15) != 0) plan->g.vec_ok = 0;
-        plan->g.web_bytes = kb;
-        const int rc = sm_match_launch(plan, pairs, d_web, d_best, (hipStream_t)stream);
-        plan->g.vec_ok = vec_ok;
-        plan->g.web_bytes = 4;
+        if (((uintptr_t)d_web & (4 * kb - 1)) != 0 || ((uintptr_t)d_best & 15) != 0) l.g.vec_ok = 0;
+        l.g.web_bytes = kb;
+        l.ev_begin = attach ? plan->t_begin[plan->timing_n] : nullptr;
+        l.ev_end = attach ? plan->t_end[plan->timing_n] : nullptr;
+        const int rc = sm_match_launch(plan, l, pairs, d_web, d_best, (hipStream_t)stream);
         if (rc) return rc;
         if (via_tmp) {
             const long long n = (long long)pairs * plan->width * plan->height;
@@ -1177,7 +1181,6 @@ extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int
     }
     if (timed && !attach) SM_HIP(hipEventRecord(plan->t_end[plan->timing_n], (hipStream_t)stream));
     if (timed) plan->timing_n++;
-    plan->launch_ev_begin = plan->launch_ev_end = nullptr;
     if (plan->pipelined) {
         // the next-but-one sm_run must not overwrite this buffer before the launch has read it
         SM_HIP(hipEventRecord(plan->ev_free[plan->cur], (hipStream_t)stream));

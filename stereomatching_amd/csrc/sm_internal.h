@@ -83,9 +83,7 @@ struct sm_plan {
     int timing_cap, timing_n, timing_every, timing_seen;
     hipEvent_t *t_begin, *t_end;
     i32 *d_web_tmp;      // int32 map for narrow results of kernels without a narrow store path
-    // the events of a timed launch, for a launcher that can attach them to the dispatch itself
-    // (sm_bs_launch: hipExtLaunchKernel); it clears them when it has done so
-    hipEvent_t launch_ev_begin, launch_ev_end;
+                         // (allocated with the plan for the kernels that need it; part of the workspace)
     i32 *d_flags;        // [0] = zero-interval flag, [1] = has-zero scratch,
                          // [2] = edge table is not of threshold form
     i32 *h_flags;        // pinned host copy of d_flags (k_publish_flags)
@@ -141,9 +139,14 @@ int sm_fail(int code, const char *fmt, ...);
 const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost, bool cap2, bool duo = false);
 int sm_bs_default_ds(int n);
 unsigned sm_bs_default_pattern(bool duo);
-int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);
+// what ONE launch adds to the plan's geometry: passed by value, the plan is not modified
+struct MatchLaunch {
+    MatchGeom g;                        // plan->g with vec_ok / web_bytes of this launch
+    hipEvent_t ev_begin, ev_end;        // non-null: attach these events to the dispatch itself
+};
+int sm_bs_launch(const sm_plan *plan, const MatchLaunch &l, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);
 int sm_bs_prepare(sm_plan *plan);        // set-up launch: code object loaded before the first real one
 
 // sm_match.hip
 int sm_match_configure(sm_plan *plan);   // fills plan->kernel / plan->g
-int sm_match_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);
+int sm_match_launch(const sm_plan *plan, const MatchLaunch &l, int pairs, i32 *d_web, i32 *d_best, hipStream_t st);

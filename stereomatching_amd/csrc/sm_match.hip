@@ -705,9 +705,8 @@ int sm_match_configure(sm_plan *plan)
 }
 
 template <int MODE>
-static void launch_tiled(const sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
+static void launch_tiled(const sm_plan *plan, const MatchGeom &g, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
 {
-    const MatchGeom &g = plan->g;
     const dim3 grid(g.tiles_x, g.tiles_y, pairs), block(g.threads);
     const bool fulld = tiled_fulld(g);
     const bool ghost = plan->border == SM_GHOST;
@@ -718,14 +717,14 @@ static void launch_tiled(const sm_plan *plan, int pairs, i32 *d_web, i32 *d_best
 #undef SM_GO
 }
 
-int sm_match_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
+int sm_match_launch(const sm_plan *plan, const MatchLaunch &l, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
 {
-    const MatchGeom &g = plan->g;
+    const MatchGeom &g = l.g;
     switch (plan->kernel) {
-    case SM_KERNEL_BS: return sm_bs_launch(plan, pairs, d_web, d_best, st);
-    case SM_KERNEL_A: launch_tiled<SM_KERNEL_A>(plan, pairs, d_web, d_best, st); break;
-    case SM_KERNEL_B: launch_tiled<SM_KERNEL_B>(plan, pairs, d_web, d_best, st); break;
-    case SM_KERNEL_C: launch_tiled<SM_KERNEL_C>(plan, pairs, d_web, d_best, st); break;
+    case SM_KERNEL_BS: return sm_bs_launch(plan, l, pairs, d_web, d_best, st);
+    case SM_KERNEL_A: launch_tiled<SM_KERNEL_A>(plan, g, pairs, d_web, d_best, st); break;
+    case SM_KERNEL_B: launch_tiled<SM_KERNEL_B>(plan, g, pairs, d_web, d_best, st); break;
+    case SM_KERNEL_C: launch_tiled<SM_KERNEL_C>(plan, g, pairs, d_web, d_best, st); break;
     default: {
         const dim3 grid(ceil_div(g.w, 256), g.h, pairs), block(256);
         hipLaunchKernelGGL(k_match_wta_generic, grid, block, 0, st, plan->d_ext, d_web, d_best,

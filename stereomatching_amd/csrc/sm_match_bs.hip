@@ -84,16 +84,16 @@ int sm_bs_prepare(sm_plan *plan)
     return SM_OK;
 }
 
-int sm_bs_launch(sm_plan *plan, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
+int sm_bs_launch(const sm_plan *plan, const MatchLaunch &l, int pairs, i32 *d_web, i32 *d_best, hipStream_t st)
 {
-    const MatchGeom &g = plan->g;
+    const MatchGeom &g = l.g;
     const void *fn = sm_bs_kernel_ptr(g.n, g.ds, g.nl * g.ds == g.D, plan->border == SM_GHOST, g.cap2 != 0, g.duo != 0);
     if (!fn) return sm_fail(SM_ERR_ARG, "bit-sliced kernel not built for n = %d, %d shifts/lane", g.n, g.ds);
     void *args[] = {(void *)&plan->d_ext, (void *)&d_web, (void *)&d_best, (void *)&g};
     hipError_t e;
-    if (plan->launch_ev_begin)      // a timed launch: the events ride on the dispatch (sm_match_wta_typed)
+    if (l.ev_begin)                 // a timed launch: the events ride on the dispatch (sm_match_wta_typed)
         e = hipExtLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(g.threads), args, g.lds_bytes, st,
-                               plan->launch_ev_begin, plan->launch_ev_end, 0);
+                               l.ev_begin, l.ev_end, 0);
     else
         e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(g.threads), args, g.lds_bytes, st);
     if (e != hipSuccess)

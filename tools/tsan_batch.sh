@@ -25,13 +25,11 @@ TSAN_OPTIONS="report_signal_unsafe=0 halt_on_error=0" timeout -k 10 200 setarch 
 echo "success path: rc=$?"
 cat gpurun_out/tsan_out.txt
 echo "reports: $(grep -c 'WARNING: ThreadSanitizer' gpurun_out/tsan_err.txt)"
-echo "reports naming the host program's own source: $(grep -c 'stereopar_batch.c' gpurun_out/tsan_err.txt)"
-grep -n "stereopar_batch.c" gpurun_out/tsan_err.txt | head -20
+echo "racing accesses inside the program's own functions: $(grep -cE '^ +#[0-9]+ (collector_main|worker_main|set_failed|sum_bytes)' gpurun_out/tsan_err.txt)"
 # the error path: an injected failure (-x) with batches in flight, two workers on device 0
 TSAN_OPTIONS="report_signal_unsafe=0 halt_on_error=0" timeout -k 10 200 setarch x86_64 -R \
   ./timing/stereopar-batch-tsan -d 0,0 -n 64 -b 1 -r 20 -x 5 gpurun_out/batch/slist.txt 0.15 7 \
   > gpurun_out/tsan_fail_out.txt 2> gpurun_out/tsan_fail_err.txt
 echo "failure path (-x 5, -d 0,0): rc=$? (1 expected), message: $(grep -c 'injected failure' gpurun_out/tsan_fail_err.txt)"
 echo "reports: $(grep -c 'WARNING: ThreadSanitizer' gpurun_out/tsan_fail_err.txt)"
-echo "reports naming the host program's own source: $(grep -c 'stereopar_batch.c' gpurun_out/tsan_fail_err.txt)"
-grep -n "stereopar_batch.c" gpurun_out/tsan_fail_err.txt | head -20
+echo "racing accesses inside the program's own functions: $(grep -cE '^ +#[0-9]+ (collector_main|worker_main|set_failed|sum_bytes)' gpurun_out/tsan_fail_err.txt)"
