@@ -19,5 +19,83 @@ struct SadGeom {
     int lds_bytes;
 };
 
-// sm_cost_qs.hip: fills *g and returns the kernel for this plan, or nullptr if the shape is not built
+#ifdef __HIPCC__
+// Stage rows ty0 - half .. ty0 - half + nsr - 1 of one pair's two gray images into LDS, [nsr][lrow]
+// bytes of the left image then [nsr][rrow] of the right one, byte 0 of a staged row = image column
+// xw - padl, with the border rule applied: wrap-around (toroidal) or zeros outside the image (ghost).
+// One-wave workgroups (tid < 64).  Shared by the SAD and the SSD kernel.
+__device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ L, const u8 *__restrict__ R,
+                                               const SadGeom &g, int xw, int ty0, int HALF, int tid)
+{
+    const int lw = g.lrow >> 2, rw = g.rrow >> 2;
+    if (g.fast_stage) {
+        // Image width a multiple of 4 and dword-aligned rows: a staged dword never straddles a border.
+        // A lane's dword columns are the same in every row, so the column arithmetic (the wrap-around
+        // or the border test) is done once, and the rows are loaded SR at a time with all loads in
+        // flight -- a load, a wait and a store per row and column cost a quarter of the kernel's
+        // instructions and left the wave waiting for memory 40 times over.
+        constexpr int SC = 4, SR = 4;                   // (lw + rw <= 256 dwords: checked by the host)
+        const u8 *col[SC];
+        int dst[SC], dstride[SC];
+        bool on[SC];
+#pragma unroll
+        for (int c = 0; c < SC; c++) {
+            const int k = tid + 64 * c;
+            const bool is_r = k >= lw;
+            const int kk = is_r ? k - lw : k;
+            const int x = xw - g.padl + 4 * kk;
+            on[c] = k < lw + rw && (!g.ghost || (x >= 0 && x < g.w));
+            const int xs = g.ghost ? x : ((x % g.w) + g.w) % g.w;
+            col[c] = (is_r ? R : L) + (on[c] ? xs : 0);
+            dst[c] = is_r ? g.nsr * lw + kk : kk;
+            dstride[c] = is_r ? rw : lw;
+            if (k >= lw + rw) dst[c] = -1;
+        }
+        for (int row0 = 0; row0 < g.nsr; row0 += SR) {
+            u32 v[SR][SC];
+#pragma unroll
+            for (int r = 0; r < SR; r++) {
+                const int y = ty0 - HALF + row0 + r;
+                const bool vy = (y >= 0 && y < g.h) || !g.ghost;
+                const int ys = g.ghost ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
+#pragma unroll
+                for (int c = 0; c < SC; c++) {
+                    v[r][c] = 0;
+                    if (on[c] && vy && row0 + r < g.nsr)
+                        v[r][c] = *reinterpret_cast<const u32 *>(col[c] + (size_t)ys * g.w);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < SR; r++)
+#pragma unroll
+                for (int c = 0; c < SC; c++)
+                    if (dst[c] >= 0 && row0 + r < g.nsr) lds[dst[c] + (row0 + r) * dstride[c]] = v[r][c];
+        }
+    } else {
+        for (int row = 0; row < g.nsr; row++) {
+            const int y = ty0 - HALF + row;
+            const bool vy = y >= 0 && y < g.h;
+            const int ys = g.ghost ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
+            for (int k = tid; k < lw + rw; k += 64) {
+                const bool is_r = k >= lw;
+                const int kk = is_r ? k - lw : k;
+                const int x = xw - g.padl + 4 * kk;
+                const u8 *src = (is_r ? R : L) + (size_t)ys * g.w;
+                u32 v = 0;
+                for (int b = 0; b < 4; b++) {
+                    const int xb = x + b;
+                    u32 p = 0;
+                    if (g.ghost) { if (vy && xb >= 0 && xb < g.w) p = src[xb]; }
+                    else p = src[((xb % g.w) + g.w) % g.w];
+                    v |= p << (8 * b);
+                }
+                (is_r ? lds + g.nsr * lw + row * rw : lds + row * lw)[kk] = v;
+            }
+        }
+    }
+}
+#endif
+
+// sm_cost_qs.hip / sm_cost_ssd.hip: fill *g and return the kernel for this plan, or nullptr if the shape is not built
 const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
+const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);

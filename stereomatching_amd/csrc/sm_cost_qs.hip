@@ -76,71 +76,7 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
     u64 *sE = reinterpret_cast<u64 *>(sR + g.nsr * rw);              // [rw]: 4 x u16 per right dword
 
     // ---- stage the tile's rows (+ window halo) with the border rule applied
-    if (g.fast_stage) {
-        // Image width a multiple of 4 and dword-aligned rows: a staged dword never straddles a border.
-        // A lane's dword columns are the same in every row, so the column arithmetic (the wrap-around
-        // or the border test) is done once, and the rows are loaded SR at a time with all loads in
-        // flight -- a load, a wait and a store per row and column cost a quarter of the kernel's
-        // instructions and left the wave waiting for memory 40 times over.
-        constexpr int SC = 4, SR = 4;                   // (lw + rw <= 256 dwords: checked by the host)
-        const u8 *col[SC];
-        int dst[SC], dstride[SC];
-        bool on[SC];
-#pragma unroll
-        for (int c = 0; c < SC; c++) {
-            const int k = tid + 64 * c;
-            const bool is_r = k >= lw;
-            const int kk = is_r ? k - lw : k;
-            const int x = xw - g.padl + 4 * kk;
-            on[c] = k < lw + rw && (!g.ghost || (x >= 0 && x < g.w));
-            const int xs = g.ghost ? x : ((x % g.w) + g.w) % g.w;
-            col[c] = (is_r ? R : L) + (on[c] ? xs : 0);
-            dst[c] = is_r ? g.nsr * lw + kk : kk;
-            dstride[c] = is_r ? rw : lw;
-            if (k >= lw + rw) dst[c] = -1;
-        }
-        for (int row0 = 0; row0 < g.nsr; row0 += SR) {
-            u32 v[SR][SC];
-#pragma unroll
-            for (int r = 0; r < SR; r++) {
-                const int y = ty0 - HALF + row0 + r;
-                const bool vy = (y >= 0 && y < g.h) || !g.ghost;
-                const int ys = g.ghost ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
-#pragma unroll
-                for (int c = 0; c < SC; c++) {
-                    v[r][c] = 0;
-                    if (on[c] && vy && row0 + r < g.nsr)
-                        v[r][c] = *reinterpret_cast<const u32 *>(col[c] + (size_t)ys * g.w);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < SR; r++)
-#pragma unroll
-                for (int c = 0; c < SC; c++)
-                    if (dst[c] >= 0 && row0 + r < g.nsr) lds[dst[c] + (row0 + r) * dstride[c]] = v[r][c];
-        }
-    } else {
-        for (int row = 0; row < g.nsr; row++) {
-            const int y = ty0 - HALF + row;
-            const bool vy = y >= 0 && y < g.h;
-            const int ys = g.ghost ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
-            for (int k = tid; k < lw + rw; k += 64) {
-                const bool is_r = k >= lw;
-                const int kk = is_r ? k - lw : k;
-                const int x = xw - g.padl + 4 * kk;
-                const u8 *src = (is_r ? R : L) + (size_t)ys * g.w;
-                u32 v = 0;
-                for (int b = 0; b < 4; b++) {
-                    const int xb = x + b;
-                    u32 p = 0;
-                    if (g.ghost) { if (vy && xb >= 0 && xb < g.w) p = src[xb]; }
-                    else p = src[((xb % g.w) + g.w) % g.w];
-                    v |= p << (8 * b);
-                }
-                (is_r ? sR + row * rw : sL + row * lw)[kk] = v;
-            }
-        }
-    }
+    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid);
     __syncthreads();
 
     // ---- lane role: residue a, shift-lane sl, pixel group j

@@ -1,0 +1,293 @@
+// sm_cost_ssd.hip -- SSD cost mode of the hot path on the byte dot-product unit.
+//
+// PARITY UNPINNED: the reference has no SSD implementation; the mode is
+// the build's own definition (stated at the top of sm_cost.hip; the checker restates it on the CPU).
+//
+//   SSD_d(x, y) = sum over the n x n window of (L - R)^2 = LL(x, y) + RR(x + d, y) - 2 LR_d(x, y)
+// with LL / RR the window sums of the squared left / right pixels -- one value per PIXEL and row,
+// not per shift -- and LR_d the window sum of the products, the only per-shift work:
+//     t  = dot4(left group, right group of the row that slides out, ...)       NG = ceil(n/4) x v_dot4_u32_u8
+//     LR = dot4(left group, right group of the row that slides in, LR) - t     NG + 1
+//     key = (RR[x + d] - 2 LR) << 8 | shift          v_mad_i32_i24 + v_lshl_or_b32, signed first-wins minimum
+// The last group of a window row holds n mod 4 pixels: the other bytes of the LEFT operand are
+// zeroed and their products vanish -- no correction term (as the SAD kernel needs) exists here.
+//
+// A lane owns PX pixels (4 apart) x 32 shifts; the right operand of shift d is the right row's dword
+// at byte x - half + d + 4 g: the four byte alignments are cut with v_alignbyte once per row and
+// alignment class and shared by the lane's pixels and the eight shifts of that class.  RR is a
+// table in LDS over the right-image positions of the tile, slid down row by row by the wave.
+//
+// Ghost border: as in the SAD kernel, rows / columns outside the image are staged as zeros in both
+// images; the columns x < half (taps left of the image, where the right image is not zero) are
+// recomputed by the masked kernel of sm_cost.hip.
+//
+// Limits: windows up to 11 x 11 (RR - 2 LR = SSD - LL lies in (-2^23, 2^23): 24 signed bits of the key)
+// and 256 shifts (the other 8).
+
+#include "sm_internal.h"
+#include "sm_cost.h"
+#include <type_traits>
+
+__device__ __forceinline__ u32 dot4(u32 a, u32 b, u32 acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
+
+template <int N, int PX>
+__global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, const u8 *__restrict__ right,
+                                                   i32 *__restrict__ web, i32 *__restrict__ best,
+                                                   const SadGeom g)
+{
+    constexpr int HALF = N / 2, FG = N / 4, RB = N % 4, NG = FG + 1;
+    constexpr u32 MASKR = RB == 1 ? 0x000000ffu : 0x00ffffffu;      // left bytes of the last group
+    constexpr int NQ = 8;                                            // quads of 4 shifts per lane: 32 shifts
+    constexpr int WL = NG + PX - 1;                                  // left operands of a lane's PX windows
+    constexpr int K = PX + NQ + NG - 2;                              // right operands of one alignment class
+    static_assert(RB == 1 || RB == 3, "odd windows");
+    static_assert(N * N * 65025 < (1 << 23), "RR - 2 LR must fit 24 signed bits of the key");
+
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.z;
+    const int xw = blockIdx.x * g.tw, ty0 = blockIdx.y * g.tile_h;
+    const size_t img = (size_t)pair * g.w * g.h;
+    const u8 *L = left + img, *R = right + img;
+    const int lw = g.lrow >> 2, rw = g.rrow >> 2;                    // dwords per staged row
+    u32 *sL = lds;                                                   // [nsr][lw]
+    u32 *sR = sL + g.nsr * lw;                                       // [nsr][rw]
+    u32 *sRR = sR + g.nsr * rw;                                      // [rrow]: RR of the current output row per right byte position
+
+    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid);
+    for (int r = tid; r < g.rrow; r += 64) sRR[r] = 0;
+    __syncthreads();
+
+    // ---- lane role: residue a, shift-lane sl, pixel group j
+    const int a = tid & 3;
+    const int sl = (tid >> 2) & (g.nl - 1);
+    const int j = tid >> (2 + g.log2nl);
+    const int x0 = xw + 4 * PX * j + a;                 // pixel p of this lane: x0 + 4 p
+    const int rho = (a - HALF) & 3;                     // (x - HALF) mod 4
+    const int bL = (x0 - HALF - rho - (xw - g.padl)) >> 2;      // dword of the window's aligned start
+    const int bR = bL + NQ * sl;                        // ... of the lane's first shift (32 sl)
+    const int r0 = x0 - (xw - g.padl) + 4 * NQ * sl;    // RR index of (pixel 0, shift 32 sl)
+    const int dlim = g.D - 4 * NQ * sl;                 // this lane's shifts below D
+
+    u32 A[PX][NQ][4];            // LR window sums of (pixel, quad, shift within the quad)
+    u32 LLs[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        LLs[p] = 0;
+#pragma unroll
+        for (int m = 0; m < NQ; m++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) A[p][m][i] = 0;
+    }
+
+    // one window row in (rn_i), one out (ro_i; none while WARM), optionally the arg-min of row y
+    auto step = [&](auto warm_tag, auto out_tag, int rn_i, int ro_i, int y) {
+        constexpr bool WARM = decltype(warm_tag)::value, OUT = decltype(out_tag)::value;
+        const u32 *rowLn = sL + rn_i * lw, *rowRn = sR + rn_i * rw;
+        const u32 *rowLo = sL + ro_i * lw, *rowRo = sR + ro_i * rw;
+
+        // RR: per right byte position q (the window centre), + the new row's horizontal sum of squares
+        // - the old row's.  Positions whose window leaves the staged row are never read.
+        for (int q = tid + HALF; q < g.rrow - HALF - 4; q += 64) {
+            const int b0 = q - HALF, wq = b0 >> 2, sh = b0 & 3;
+            u32 sn = 0, so = 0;
+#pragma unroll
+            for (int gp = 0; gp < NG; gp++) {
+                u32 v = __builtin_amdgcn_alignbyte(rowRn[wq + gp + 1], rowRn[wq + gp], sh);
+                if (gp == FG) v &= MASKR;
+                sn = dot4(v, v, sn);
+                if (!WARM) {
+                    u32 u = __builtin_amdgcn_alignbyte(rowRo[wq + gp + 1], rowRo[wq + gp], sh);
+                    if (gp == FG) u &= MASKR;
+                    so = dot4(u, u, so);
+                }
+            }
+            sRR[q] += sn - so;
+        }
+        __syncthreads();
+
+        // left operands of this lane's PX windows: NG groups each, 4 pixels apart -> NG + PX - 1 dwords
+        u32 un[WL], unp[PX], uo[WL], uop[PX];
+        {
+            u32 t[WL + 1];
+#pragma unroll
+            for (int m = 0; m <= WL; m++) t[m] = rowLn[bL + m];
+#pragma unroll
+            for (int m = 0; m < WL; m++) un[m] = __builtin_amdgcn_alignbyte(t[m + 1], t[m], rho);
+#pragma unroll
+            for (int p = 0; p < PX; p++) unp[p] = un[p + FG] & MASKR;
+            if (!WARM) {
+#pragma unroll
+                for (int m = 0; m <= WL; m++) t[m] = rowLo[bL + m];
+#pragma unroll
+                for (int m = 0; m < WL; m++) uo[m] = __builtin_amdgcn_alignbyte(t[m + 1], t[m], rho);
+#pragma unroll
+                for (int p = 0; p < PX; p++) uop[p] = uo[p + FG] & MASKR;
+            }
+        }
+        // LL of the lane's pixels (only `best` needs it: the arg-min does not depend on it)
+#pragma unroll
+        for (int p = 0; p < PX; p++) {
+            u32 sn = 0, so = 0;
+#pragma unroll
+            for (int gp = 0; gp < NG; gp++) {
+                const u32 v = gp == FG ? unp[p] : un[p + gp];
+                sn = dot4(v, v, sn);
+                if (!WARM) { const u32 u = gp == FG ? uop[p] : uo[p + gp]; so = dot4(u, u, so); }
+            }
+            LLs[p] += sn - so;
+        }
+
+        i32 run[PX];
+#pragma unroll
+        for (int p = 0; p < PX; p++) run[p] = 0x7fffff00;
+        int dl = dlim;                      // (opaque: keeps the per-lane validity tests inside the row loop)
+        asm volatile("" : "+v"(dl));
+
+        // the four byte alignments of the right row, one after the other: shift 4 m + i of a lane reads
+        // the right row at dword bR + p + m + g + ((rho + i) >> 2), byte (rho + i) & 3
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ci = (rho + i) & 3, oi = (rho + i) >> 2;
+            u32 rn[K], ro[K];
+            {
+                u32 t[K + 1];
+#pragma unroll
+                for (int k = 0; k <= K; k++) t[k] = rowRn[bR + oi + k];
+#pragma unroll
+                for (int k = 0; k < K; k++) rn[k] = __builtin_amdgcn_alignbyte(t[k + 1], t[k], ci);
+                if (!WARM) {
+#pragma unroll
+                    for (int k = 0; k <= K; k++) t[k] = rowRo[bR + oi + k];
+#pragma unroll
+                    for (int k = 0; k < K; k++) ro[k] = __builtin_amdgcn_alignbyte(t[k + 1], t[k], ci);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NQ; m++) {
+                u32 rr[PX];
+                if (OUT) {
+#pragma unroll
+                    for (int p = 0; p < PX; p++) rr[p] = sRR[r0 + 4 * (p + m) + i];
+                }
+#pragma unroll
+                for (int p = 0; p < PX; p++) {
+                    u32 t = 0;
+                    if (!WARM) {
+#pragma unroll
+                        for (int gp = 0; gp < NG; gp++) t = dot4(gp == FG ? uop[p] : uo[p + gp], ro[p + m + gp], t);
+                    }
+                    u32 acc = A[p][m][i];
+#pragma unroll
+                    for (int gp = 0; gp < NG; gp++) acc = dot4(gp == FG ? unp[p] : un[p + gp], rn[p + m + gp], acc);
+                    acc -= t;
+                    asm volatile("" : "+v"(acc));           // (pinned, as in the SAD kernel)
+                    A[p][m][i] = acc;
+                    if (OUT) {
+                        // key: (RR - 2 LR) << 8 | shift within the lane, signed; the smallest wins, i.e. the
+                        // lowest SSD (LL is the same for all shifts of a pixel) and among equals the first shift
+                        const i32 gval = __mul24((i32)acc, -2) + (i32)rr[p];     // RR - 2 LR (-> v_mad_i32_i24)
+                        i32 key = (i32)(((u32)gval << 8) | (u32)(4 * m + i));
+                        if (4 * m + 3 >= g.q_tail) {        // uniform: the last shift-lane may hold shifts >= D
+                            if (4 * m + i >= dl) key = 0x7fffff00;   // (adding a lane's base shift below cannot wrap)
+                        }
+                        run[p] = min(run[p], key);
+                        asm volatile("" : "+v"(run[p]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        if (OUT) {
+#pragma unroll
+            for (int p = 0; p < PX; p++) {
+                i32 key = run[p] + 4 * NQ * sl;             // the low 8 bits become the shift itself
+                for (int k = 0; k < g.log2nl; k++) key = min(key, __shfl_xor(key, 4 << k));
+                const int x = x0 + 4 * p;
+                if (sl == 0 && x < g.w) {
+                    const size_t o = ((size_t)pair * g.h + y) * g.w + x;
+                    web[o] = (key & 255) + 1;
+                    if (best) best[o] = (key >> 8) + (i32)LLs[p];
+                }
+            }
+        }
+        __syncthreads();            // RR is updated by the next step
+    };
+
+    const int rows_out = min(g.tile_h, g.h - ty0);
+    using T = std::true_type;
+    using F = std::false_type;
+    // staged row e is image row ty0 - HALF + e: output row t has window rows t .. t + N - 1
+#pragma unroll 1
+    for (int e = 0; e < N - 1; e++) step(T{}, F{}, e, 0, 0);
+    step(T{}, T{}, N - 1, 0, ty0);
+#pragma unroll 1
+    for (int t = 1; t < rows_out; t++) step(F{}, T{}, t + N - 1, t - 1, ty0 + t);
+}
+
+// ---------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------
+
+template <int N>
+static const void *ssd_ptr(int px)
+{
+    if (px == 2) return (const void *)k_ssd_dot<N, 2>;
+    if (px == 4) return (const void *)k_ssd_dot<N, 4>;
+    return nullptr;
+}
+
+// fills g and returns the kernel, or nullptr if this shape is not built (caller falls back)
+const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *out)
+{
+    SadGeom g;
+    g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
+    const int half = plan->square_width / 2, n = 2 * half + 1;
+    g.ghost = plan->border == SM_GHOST;
+    if (n < 3 || n > 11 || g.D > 256 || plan->opt.cost_kernel == 1) return nullptr;
+    const int nql = 8;
+    int px = 4;             // (2: narrower tiles, more set-up per pixel; measured slower at every BASELINE configuration)
+    if (plan->opt.cost_pixels_per_lane == 2 || plan->opt.cost_pixels_per_lane == 4) px = plan->opt.cost_pixels_per_lane;
+    g.nl = 1; g.log2nl = 0;
+    while (g.nl * 4 * nql < g.D) { g.nl <<= 1; g.log2nl++; }
+    g.tw = 4 * px * (16 / g.nl);
+    g.tiles_x = (g.w + g.tw - 1) / g.tw;
+    const int ng = n / 4 + 1;
+    g.padl = 4 * ((half + 3 + 3) / 4);
+    // left row: dwords bL .. bL + NG + PX - 1; right: bR + 1 + (PX + NQ + NG - 2) of the last shift-lane
+    g.lrow = 8 * ((g.padl + g.tw + 4 * (ng + 1) + 7) / 8);
+    g.rrow = 8 * ((g.padl + g.tw + 4 * (g.nl * nql + ng + 3) + 7) / 8);
+    g.q_tail = g.D - 4 * nql * (g.nl - 1);          // shifts of the last shift-lane below D
+    g.q_last = nql - 1;
+    const int slots = 256 * 4 * 2;
+    int best_th = 0; double best_cost = 0;
+    for (int th = 8; th <= 128; th += 4) {
+        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)g.rrow;
+        if (lds > 160 * 1024 / 8) break;
+        const long long tiles = (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs;
+        const long long rounds = (tiles + slots - 1) / slots;
+        const double cost = (double)rounds * (th + 0.45 * (n - 1) + 2.0);
+        if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
+    }
+    if (!best_th) return nullptr;
+    if (plan->opt.cost_tile_h > 0) best_th = plan->opt.cost_tile_h;
+    g.tile_h = best_th < g.h ? best_th : g.h;
+    g.tiles_y = (g.h + g.tile_h - 1) / g.tile_h;
+    g.nsr = g.tile_h + n - 1;
+    g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0 &&
+                   g.lrow + g.rrow <= 4 * 256;
+    g.lds_bytes = g.nsr * (g.lrow + g.rrow) + 4 * g.rrow;
+    g.nql = nql; g.px = px;
+    const void *fn = nullptr;
+    switch (n) {
+    case 3: fn = ssd_ptr<3>(px); break;
+    case 5: fn = ssd_ptr<5>(px); break;
+    case 7: fn = ssd_ptr<7>(px); break;
+    case 9: fn = ssd_ptr<9>(px); break;
+    case 11: fn = ssd_ptr<11>(px); break;
+    }
+    *out = g;
+    return fn;
+}

@@ -700,46 +700,49 @@ SAD_QS = [  # (w, h, D, S): quads per lane / shift-lanes / pixels per lane of th
 
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 @pytest.mark.parametrize("tile_h", [0, 3])
+@pytest.mark.parametrize("cost", ["sad", "ssd"])
 @pytest.mark.parametrize("w,h,d,sw", SAD_QS)
-def test_quad_sad_kernel_matches_own_oracle(hip, mode, tile_h, w, h, d, sw):
-    """k_sad_qs: every shape of (quads per lane, shift-lanes), windows 3 .. 15, both borders, tiles of
-    3 rows (several slides per wave, a ragged last tile) and the plan's own height, unaligned input"""
+def test_quad_sad_kernel_matches_own_oracle(hip, mode, tile_h, cost, w, h, d, sw):
+    """k_sad_qs / k_ssd_dot: every shape of (quads per lane, shift-lanes), windows 3 .. 15 (SSD: .. 11, the
+    larger ones take the general kernel), both borders, tiles of 3 rows (several slides per wave, a
+    ragged last tile) and the plan's own height, unaligned input"""
     left, right = make_pair(w, h, d, seed=w * 3 + d, kind="noise" if (w + d) % 3 == 0 else "scene")
     if (w + h) % 2:             # saturate some pixels: 0 and 255 are the masked-SAD corner cases
         left[::3, ::5] = 0; left[1::4, 2::7] = 255; right[::5, ::3] = 255; right[2::3, 1::4] = 0
     plan = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_tile_h=tile_h))
-    web, best = plan.cost_wta(dev(left), dev(right), "sad")
-    ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, "sad")
+    web, best = plan.cost_wta(dev(left), dev(right), cost)
+    ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, cost)
     assert np.array_equal(host(web)[0], ow), (mode, w, h, d, sw)
     assert np.array_equal(host(best)[0], ob), (mode, w, h, d, sw)
-    # the general masked kernel (what SSD and windows beyond 15 x 15 use) on the same input
+    # the general masked kernel (windows beyond 15 x 15 / 11 x 11, more than 512 shifts) on the same input
     gen = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_kernel=1))
-    web2, best2 = gen.cost_wta(dev(left), dev(right), "sad")
+    web2, best2 = gen.cost_wta(dev(left), dev(right), cost)
     assert torch.equal(web2, web) and torch.equal(best2, best)
     plan.close(); gen.close()
 
 
-def test_quad_sad_unaligned_images_and_batches(hip):
+@pytest.mark.parametrize("cost", ["sad", "ssd"])
+def test_quad_sad_unaligned_images_and_batches(hip, cost):
     """image pointers that are not dword-aligned take the bytewise staging path; pairs of a batch
     are independent launches in z"""
     w, h, d, sw, n = 120, 50, 64, 9, 3
     pairs = [make_pair(w, h, d, seed=90 + i) for i in range(n)]
     left = np.stack([p[0] for p in pairs]); right = np.stack([p[1] for p in pairs])
     plan = hip.StereoPlan(w, h, d, sw, "toroidal", max_pairs=n)
-    web, best = plan.cost_wta(dev(left), dev(right), "sad")
+    web, best = plan.cost_wta(dev(left), dev(right), cost)
     buf_l = torch.empty(n * w * h + 1, dtype=torch.uint8, device="cuda")
     buf_r = torch.empty(n * w * h + 3, dtype=torch.uint8, device="cuda")
     ul, ur = buf_l[1:].view(n, h, w), buf_r[3:].view(n, h, w)
     ul.copy_(dev(left)); ur.copy_(dev(right))
-    web_u, best_u = plan.cost_wta(ul, ur, "sad")
+    web_u, best_u = plan.cost_wta(ul, ur, cost)
     for i in range(n):
-        ob, ow = oracle.cost_hot_path(pairs[i][0], pairs[i][1], d, sw, "toroidal", "sad")
+        ob, ow = oracle.cost_hot_path(pairs[i][0], pairs[i][1], d, sw, "toroidal", cost)
         assert np.array_equal(host(web)[i], ow) and np.array_equal(host(best)[i], ob), i
     assert torch.equal(web_u, web) and torch.equal(best_u, best)
     plan.close()
 
 
-@pytest.mark.parametrize("cfg,cost", [("C3", "sad"), ("C5", "sad"), ("C5", "ssd")])
+@pytest.mark.parametrize("cfg,cost", [("C3", "sad"), ("C5", "sad"), ("C3", "ssd"), ("C5", "ssd")])
 def test_cost_mode_4k_full_image_vs_own_oracle(hip, cfg, cost):
     """The 4K configurations in the SAD / SSD cost mode (PARITY UNPINNED: the build's own CPU
     definition is the only oracle), EVERY pixel of web and best: the definition run on row bands

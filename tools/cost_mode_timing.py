@@ -6,13 +6,15 @@ import torch
 from stereomatching_amd import pipeline
 from stereomatching_amd.synth import CONFIGS, make_pair
 
+from tools._options import from_env          # SM_COST_PX / SM_COST_TILE_H / SM_COST_KERNEL in this tool's environment
 cfgs = [a for a in sys.argv[1:] if a in CONFIGS] or ["C2", "C3", "C5"]
+costs = [a for a in sys.argv[1:] if a in ("sad", "ssd")] or ["sad", "ssd"]
 for cfg in cfgs:
     w, h, d, sw, mode = CONFIGS[cfg]
     l, r = make_pair(w, h, d, seed=1)
     L, R = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
-    plan = pipeline.StereoPlan(w, h, d, sw, mode)
-    for cost in ("sad", "ssd"):
+    plan = pipeline.StereoPlan(w, h, d, sw, mode, options=from_env() or None)
+    for cost in costs:
         for _ in range(5):
             plan.cost_wta(L, R, cost, want_best=False)
         torch.cuda.synchronize()
