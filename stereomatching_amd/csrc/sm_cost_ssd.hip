@@ -13,8 +13,9 @@
 // zeroed and their products vanish -- no correction term (as the SAD kernel needs) exists here.
 //
 // A lane owns PX pixels (4 apart) x 32 shifts; the right operand of shift d is the right row's dword
-// at byte x - half + d + 4 g: the four byte alignments are cut with v_alignbyte once per row and
-// alignment class and shared by the lane's pixels and the eight shifts of that class.  RR is a
+// at byte x - half + d + 4 g: the row is re-based to the lane's window start once, then its four byte
+// alignments are cut with v_alignbyte once per row and shared by the lane's pixels and the eight shifts
+// of that alignment.  RR is a
 // table in LDS over the right-image positions of the tile, slid down row by row by the wave.
 //
 // Ghost border: as in the SAD kernel, rows / columns outside the image are staged as zeros in both
@@ -144,33 +145,42 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
         int dl = dlim;                      // (opaque: keeps the per-lane validity tests inside the row loop)
         asm volatile("" : "+v"(dl));
 
-        // the four byte alignments of the right row, one after the other: shift 4 m + i of a lane reads
-        // the right row at dword bR + p + m + g + ((rho + i) >> 2), byte (rho + i) & 3
+        // The right row, re-based to the lane's window start once (byte offset rho, per lane): after
+        // that shift 4 m + i of pixel p, group g reads dword p + m + g of the copy shifted by i more
+        // bytes -- the same i for every lane, and no dword of the row is read from LDS twice.
+        u32 wn[K + 1], wo[K + 1];
+        {
+            u32 t[K + 2];
+#pragma unroll
+            for (int k = 0; k < K + 2; k++) t[k] = rowRn[bR + k];
+#pragma unroll
+            for (int k = 0; k <= K; k++) wn[k] = __builtin_amdgcn_alignbyte(t[k + 1], t[k], rho);
+            if (!WARM) {
+#pragma unroll
+                for (int k = 0; k < K + 2; k++) t[k] = rowRo[bR + k];
+#pragma unroll
+                for (int k = 0; k <= K; k++) wo[k] = __builtin_amdgcn_alignbyte(t[k + 1], t[k], rho);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int ci = (rho + i) & 3, oi = (rho + i) >> 2;
             u32 rn[K], ro[K];
-            {
-                u32 t[K + 1];
 #pragma unroll
-                for (int k = 0; k <= K; k++) t[k] = rowRn[bR + oi + k];
+            for (int k = 0; k < K; k++) {
+                rn[k] = i ? __builtin_amdgcn_alignbyte(wn[k + 1], wn[k], i) : wn[k];
+                if (!WARM) ro[k] = i ? __builtin_amdgcn_alignbyte(wo[k + 1], wo[k], i) : wo[k];
+            }
+            // RR of (pixel p, shift 4 m + i) is entry r0 + 4 (p + m) + i: a window of PX entries slides over m
+            u32 rr[PX + 1];
+            if (OUT) {
 #pragma unroll
-                for (int k = 0; k < K; k++) rn[k] = __builtin_amdgcn_alignbyte(t[k + 1], t[k], ci);
-                if (!WARM) {
-#pragma unroll
-                    for (int k = 0; k <= K; k++) t[k] = rowRo[bR + oi + k];
-#pragma unroll
-                    for (int k = 0; k < K; k++) ro[k] = __builtin_amdgcn_alignbyte(t[k + 1], t[k], ci);
-                }
+                for (int p = 0; p < PX; p++) rr[p] = sRR[r0 + 4 * p + i];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < NQ; m++) {
-                u32 rr[PX];
-                if (OUT) {
-#pragma unroll
-                    for (int p = 0; p < PX; p++) rr[p] = sRR[r0 + 4 * (p + m) + i];
-                }
+                if (OUT && m + 1 < NQ) rr[PX] = sRR[r0 + 4 * (PX + m) + i];
 #pragma unroll
                 for (int p = 0; p < PX; p++) {
                     u32 t = 0;
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                     if (OUT) {
                         // key: (RR - 2 LR) << 8 | shift within the lane, signed; the smallest wins, i.e. the
                         // lowest SSD (LL is the same for all shifts of a pixel) and among equals the first shift
-                        const i32 gval = __mul24((i32)acc, -2) + (i32)rr[p];     // RR - 2 LR (-> v_mad_i32_i24)
+                        const i32 gval = __mul24((i32)acc, -2) + (i32)rr[p];     // RR - 2 LR
                         i32 key = (i32)(((u32)gval << 8) | (u32)(4 * m + i));
                         if (4 * m + 3 >= g.q_tail) {        // uniform: the last shift-lane may hold shifts >= D
                             if (4 * m + i >= dl) key = 0x7fffff00;   // (adding a lane's base shift below cannot wrap)
@@ -195,6 +205,10 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                         run[p] = min(run[p], key);
                         asm volatile("" : "+v"(run[p]));
                     }
+                }
+                if (OUT) {
+#pragma unroll
+                    for (int p = 0; p < PX; p++) rr[p] = rr[p + 1];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -28,8 +28,10 @@ COUNTS = Path(__file__).resolve().parent / "valu_counts.json"
 def variant_key(geom: dict, num_shifts: int, border: int, want_best: bool) -> str:
     fulld = geom["shift_lanes"] * geom["shifts_per_lane"] == num_shifts
     duo = ":duo" if geom["kernel"] == 4 and geom.get("waves_per_workgroup", 1) == 2 else ""
+    # the build capped at two waves per SIMD is code of its own (the register cap can move spills)
+    cap2 = ":cap2" if geom["kernel"] == 4 and geom.get("two_wave_variant") else ""
     return (f"k{geom['kernel']}:n{geom['window']}:ds{geom['shifts_per_lane']}:nl{geom['shift_lanes']}:"
-            f"{'ghost' if border else 'toroidal'}:fulld{int(fulld)}:best{int(bool(want_best))}{duo}")
+            f"{'ghost' if border else 'toroidal'}:fulld{int(fulld)}:best{int(bool(want_best))}{duo}{cap2}")
 
 
 def waves_and_rows(geom: dict, height: int, pairs: int):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun -- 'bash tools/fit_valu_model.sh'     (PMC passes only, one counter set, no trace domains
 # beyond --kernel-trace)  ->  gpurun_out/valu_fit/<cfg>_<pairs>_<best>_<tile_h>/{meta.json,*.csv}
-# then here:  python tools/fit_valu_model.py gpurun_out/valu_fit profiles/r02/valu_fit.json
+# then here:  python tools/fit_valu_model.py gpurun_out/valu_fit profiles/r03/valu_fit.json
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/valu_fit; rm -rf $OUT; mkdir -p $OUT
 CASES=${CASES:-"C3:1:0 C3:1:1 C2:1:0 C4:8:0 C5:1:0 REF4K:1:0"}

@@ -13,12 +13,12 @@ typedef unsigned u32;
 
 enum { OP_BITOP3, OP_QSAD, OP_MQSAD, OP_MQSAD32, OP_SAD, OP_PKSUB, OP_PKMIN, OP_MINU32, OP_MIN3,
        OP_MADU16, OP_ANDOR, OP_LSHLOR, OP_PERM, OP_DOT4, OP_ALIGNBYTE, OP_PKMAD, OP_SUBU32, OP_MSAD,
-       OP_QSAD_MIX, OP_COUNT };
+       OP_QSAD_MIX, OP_BSMIX, OP_COUNT };
 static const char *op_name[OP_COUNT] = {
     "v_bitop3_b32", "v_qsad_pk_u16_u8", "v_mqsad_pk_u16_u8", "v_mqsad_u32_u8", "v_sad_u8", "v_pk_sub_u16",
     "v_pk_min_u16", "v_min_u32", "v_min3_u32", "v_mad_u32_u16", "v_and_or_b32", "v_lshl_or_b32", "v_perm_b32",
     "v_dot4_u32_u8", "v_alignbyte_b32", "v_pk_mad_u16", "v_sub_u32", "v_msad_u8",
-    "mix: 6 qsad + 2 pk_sub + 4 and_or/lshl_or + 2 min3"};
+    "mix: 6 qsad + 2 pk_sub + 4 and_or/lshl_or + 2 min3", "mix: 15 v_bitop3 + 1 v_alignbit (the bit-sliced kernel's)"};
 
 template <int OP, int W>
 __global__ __launch_bounds__(64) void k_rate(u32 *out, u64 *info, int iters)
@@ -62,6 +62,10 @@ __global__ __launch_bounds__(64) void k_rate(u32 *out, u64 *info, int iters)
                 if (OP == OP_ALIGNBYTE) asm volatile("v_alignbyte_b32 %0, %0, %1, %2" : "+v"(lo) : "v"(x), "v"(y));
                 if (OP == OP_PKMAD) asm volatile("v_pk_mad_u16 %0, %0, %1, %2 clamp" : "+v"(lo) : "v"(x), "v"(y));
                 if (OP == OP_SUBU32) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(lo) : "v"(x));
+                if (OP == OP_BSMIX) {
+                    if ((r * ILP + i) % 16 == 15) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(lo) : "v"(x));
+                    else asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(lo) : "v"(x), "v"(y));
+                }
             }
             if (OP == OP_QSAD_MIX) {
                 // the per-(pixel, 4 shifts) row step of a QSAD block matcher, 2 items side by side
@@ -99,10 +103,11 @@ __global__ __launch_bounds__(64) void k_rate(u32 *out, u64 *info, int iters)
     if (threadIdx.x == 0) info[blockIdx.x] = t1 - t0;
 }
 
+static int g_iters = 200;
 template <int OP, int W>
 static void run(u32 *out, u64 *info)
 {
-    const int iters = 200;
+    const int iters = g_iters;
     const int grid = 256 * 4 * W;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -120,8 +125,9 @@ static void run(u32 *out, u64 *info)
     double cyc = 0;
     for (int b = 0; b < grid; b++) cyc += (double)h[b];
     const double n_instr = (double)iters * 16 * (OP == OP_QSAD_MIX ? 28 : 8);
-    printf("%-50s %d wave(s)/SIMD: %6.2f shader cycles/instr/wave  -> %5.2f per SIMD   (%.3f ns/instr/SIMD wall)\n",
-           op_name[OP], W, cyc / grid / n_instr, cyc / grid / n_instr / W, best * 1e6 / (n_instr * W));
+    printf("%-50s %d wave(s)/SIMD: %6.2f shader cycles/instr/wave  -> %5.2f per SIMD   (%.3f ns/instr/SIMD wall, %.2f GHz, %.0f G wave-instr/s chip-wide)\n",
+           op_name[OP], W, cyc / grid / n_instr, cyc / grid / n_instr / W, best * 1e6 / (n_instr * W),
+           cyc / grid / (best * 1e6), 1024.0 / (best * 1e6 / (n_instr * W)));
 }
 
 template <int OP> static void both(u32 *out, u64 *info) { run<OP, 1>(out, info); run<OP, 2>(out, info); }
@@ -198,5 +204,10 @@ int main()
     both<OP_PKMAD>(out, info); both<OP_SUBU32>(out, info); both<OP_QSAD_MIX>(out, info);
     run<OP_QSAD, 3>(out, info); run<OP_QSAD, 4>(out, info); run<OP_QSAD_MIX, 3>(out, info); run<OP_QSAD_MIX, 4>(out, info);
     run<OP_BITOP3, 3>(out, info); run<OP_BITOP3, 4>(out, info); run<OP_LSHLOR, 3>(out, info); run<OP_LSHLOR, 4>(out, info);
+    // the integer-VALU ceiling the chip actually holds: long launches (~100 us, the match kernel's length), 1 .. 4 waves per SIMD
+    g_iters = 400;
+    printf("-- long launches (%d iterations): what a full-rate stream sustains, by waves per SIMD\n", g_iters);
+    run<OP_BITOP3, 1>(out, info); run<OP_BITOP3, 2>(out, info); run<OP_BITOP3, 3>(out, info); run<OP_BITOP3, 4>(out, info);
+    run<OP_BSMIX, 1>(out, info); run<OP_BSMIX, 2>(out, info); run<OP_BSMIX, 3>(out, info); run<OP_BSMIX, 4>(out, info);
     return 0;
 }
