@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_cost_wta(const u8 *__restrict__ left,
         const int y = ty0 - half + row;
         const bool vy = y >= 0 && y < g.h;
         const int ys = GHOST ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
-        for (int b = tid; b < g.lrow + g.rrow; b += 256) {
+        for (int b = tid; b < g.lrow + g.rrow; b += (int)blockDim.x) {
             const bool is_r = b >= g.lrow;
             const int bb = is_r ? b - g.lrow : b;
             const int x = tx0 - g.pad + bb;
@@ -258,7 +258,16 @@ static int launch_general(sm_plan *plan, const uint8_t *d_gray_left, const uint8
                        "(got %dx%d, %d)", g.n, g.n, g.D);
     g.nl = 1; g.log2nl = 0;
     while (g.nl * SMC_DS < g.D) { g.nl <<= 1; g.log2nl++; }
+    // whole image: 256 threads = 256 / nl pixel groups per workgroup; the ghost strip: only the
+    // groups that hold its few columns (a narrow tile: little to stage), rounded up to whole waves
+    int threads = 256;
     g.groups = 256 / g.nl;
+    if (strip_cols > 0) {
+        const int need = (strip_cols + SMC_PX - 1) / SMC_PX;
+        if (need < g.groups) g.groups = need;
+        threads = 64 * ((g.groups * g.nl + 63) / 64);
+        g.groups = threads / g.nl;
+    }
     g.tw = g.groups * SMC_PX;
     g.pad = 4 * ((g.half + 3) / 4);
     int nwd = (g.n + 3 + 3) / 4;       // dwords holding the n + 3 window bytes of a lane
@@ -273,7 +282,9 @@ static int launch_general(sm_plan *plan, const uint8_t *d_gray_left, const uint8
         g.tiles_x = (strip_cols + g.tw - 1) / g.tw;
     }
     int th = 64;
-    while (th > 8 && (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs < 1024) th >>= 1;
+    // (the strip is a few hundred short workgroups whatever the tile height: its duration is one
+    // workgroup's latency, so it takes the shortest tiles)
+    while (th > (strip_cols > 0 ? 2 : 8) && (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs < (strip_cols > 0 ? 4096 : 1024)) th >>= 1;
     while ((th + g.n - 1) * (g.lrow + g.rrow) > 60 * 1024 && th > 1) th >>= 1;
     th = th < g.h ? th : g.h;
     g.tile_h = th;
@@ -291,7 +302,7 @@ static int launch_general(sm_plan *plan, const uint8_t *d_gray_left, const uint8
     default: fn = cost_ptr<7>(ssd, ghost); break;
     }
     void *args[] = {(void *)&d_gray_left, (void *)&d_gray_right, (void *)&d_web, (void *)&d_best, (void *)&g};
-    const hipError_t e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(256), args,
+    const hipError_t e = hipLaunchKernel(fn, dim3(g.tiles_x, g.tiles_y, pairs), dim3(threads), args,
                                          (size_t)g.nsr * (g.lrow + g.rrow), stream);
     if (e != hipSuccess) return sm_fail(SM_ERR_HIP, "sm_cost_wta: %s", hipGetErrorString(e));
     return SM_OK;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
                     acc = pk4_sub(acc, t);
                     // (pinned: nothing of a quad may sink below the quads nested in it -- the compiler
                     // otherwise reads all operands on the way in, spilling them, and computes on the way out)
-                    asm volatile("" : "+v"(acc));
+                    asm volatile("" : : "v"(acc));          // (a use only: an output would cost a wait state behind it)
                     A[i][q] = acc;
                     if (OUT) {
                         // keys: window sum << 16 | shift within the chunk; the smallest wins, i.e. the
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
                         r = min(min(r, k2), k3);
                         // (pinned: the compiler otherwise sinks the whole min chain to the end of the row
                         // and keeps the keys of every quad alive until then)
-                        asm volatile("" : "+v"(r));
+                        asm volatile("" : : "v"(r));
                         runc[q / CH][i] = r;
                     }
                 }

@@ -8,7 +8,7 @@
 // not per shift -- and LR_d the window sum of the products, the only per-shift work:
 //     t  = dot4(left group, right group of the row that slides out, ...)       NG = ceil(n/4) x v_dot4_u32_u8
 //     LR = dot4(left group, right group of the row that slides in, LR) - t     NG + 1
-//     key = (RR[x + d] - 2 LR) << 8 | shift          v_mad_i32_i24 + v_lshl_or_b32, signed first-wins minimum
+//     key = (RR[x + d] << 8 | shift) - (LR << 9)     = (RR - 2 LR) << 8 | shift; signed first-wins minimum
 // The last group of a window row holds n mod 4 pixels: the other bytes of the LEFT operand are
 // zeroed and their products vanish -- no correction term (as the SAD kernel needs) exists here.
 //
@@ -31,7 +31,7 @@
 
 __device__ __forceinline__ u32 dot4(u32 a, u32 b, u32 acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
 
-template <int N, int PX>
+template <int N, int PX, bool FULLD>
 __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, const u8 *__restrict__ right,
                                                    i32 *__restrict__ web, i32 *__restrict__ best,
                                                    const SadGeom g)
@@ -53,10 +53,17 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
     const int lw = g.lrow >> 2, rw = g.rrow >> 2;                    // dwords per staged row
     u32 *sL = lds;                                                   // [nsr][lw]
     u32 *sR = sL + g.nsr * lw;                                       // [nsr][rw]
-    u32 *sRR = sR + g.nsr * rw;                                      // [rrow]: RR of the current output row per right byte position
+    // RR of the current output row, [nloc][nl]: entry (l, sl) is the window sum of squares centred on
+    // right byte position l + 32 sl of the staged row -- one copy per shift-lane, interleaved, so that
+    // the lanes of a wave (which differ by multiples of 32 positions) read 32 different banks and a
+    // lane's entries are a constant stride apart (the plain [position] table cost 8-way conflicts:
+    // 178 M conflict cycles against 35 M LDS cycles at C5)
+    u32 *sRR = sR + g.nsr * rw;
+    u32 *sD = sRR + (g.padl + g.tw + 32) * g.nl;                     // [rrow, skewed]: this row step's differences by position
 
     smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid);
-    for (int r = tid; r < g.rrow; r += 64) sRR[r] = 0;
+    const int nloc = g.padl + g.tw + 32;
+    for (int r = tid; r < nloc * g.nl; r += 64) sRR[r] = 0;
     __syncthreads();
 
     // ---- lane role: residue a, shift-lane sl, pixel group j
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
     const int rho = (a - HALF) & 3;                     // (x - HALF) mod 4
     const int bL = (x0 - HALF - rho - (xw - g.padl)) >> 2;      // dword of the window's aligned start
     const int bR = bL + NQ * sl;                        // ... of the lane's first shift (32 sl)
-    const int r0 = x0 - (xw - g.padl) + 4 * NQ * sl;    // RR index of (pixel 0, shift 32 sl)
+    const int r0 = (x0 - (xw - g.padl)) * g.nl + sl;    // RR entry of (pixel 0, shift 32 sl); one position further: + nl
     const int dlim = g.D - 4 * NQ * sl;                 // this lane's shifts below D
 
     u32 A[PX][NQ][4];            // LR window sums of (pixel, quad, shift within the quad)
@@ -88,7 +95,10 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
         const u32 *rowLo = sL + ro_i * lw, *rowRo = sR + ro_i * rw;
 
         // RR: per right byte position q (the window centre), + the new row's horizontal sum of squares
-        // - the old row's.  Positions whose window leaves the staged row are never read.
+        // - the old row's.  Two phases, both free of bank conflicts: the differences by position into a
+        // flat row (skewed by 4 words per 32 positions), then every table entry (l, s) adds the one of
+        // position l + 32 s -- consecutive lanes, consecutive entries.  (Updating the interleaved table by
+        // position instead put 8 lanes on each bank: 99 M conflict cycles against 46 M LDS cycles at C5.)
         for (int q = tid + HALF; q < g.rrow - HALF - 4; q += 64) {
             const int b0 = q - HALF, wq = b0 >> 2, sh = b0 & 3;
             u32 sn = 0, so = 0;
@@ -103,7 +113,12 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                     so = dot4(u, u, so);
                 }
             }
-            sRR[q] += sn - so;
+            sD[q + 4 * (q >> 5)] = sn - so;
+        }
+        __syncthreads();
+        for (int e = tid; e < nloc * g.nl; e += 64) {
+            const int q = (e >> g.log2nl) + 32 * (e & (g.nl - 1));
+            if (q >= HALF && q < g.rrow - HALF - 4) sRR[e] += sD[q + 4 * (q >> 5)];
         }
         __syncthreads();
 
@@ -175,12 +190,12 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
             u32 rr[PX + 1];
             if (OUT) {
 #pragma unroll
-                for (int p = 0; p < PX; p++) rr[p] = sRR[r0 + 4 * p + i];
+                for (int p = 0; p < PX; p++) rr[p] = sRR[r0 + (4 * p + i) * g.nl];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < NQ; m++) {
-                if (OUT && m + 1 < NQ) rr[PX] = sRR[r0 + 4 * (PX + m) + i];
+                if (OUT && m + 1 < NQ) rr[PX] = sRR[r0 + (4 * (PX + m) + i) * g.nl];
 #pragma unroll
                 for (int p = 0; p < PX; p++) {
                     u32 t = 0;
@@ -192,18 +207,22 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
 #pragma unroll
                     for (int gp = 0; gp < NG; gp++) acc = dot4(gp == FG ? unp[p] : un[p + gp], rn[p + m + gp], acc);
                     acc -= t;
-                    asm volatile("" : "+v"(acc));           // (pinned, as in the SAD kernel)
                     A[p][m][i] = acc;
                     if (OUT) {
                         // key: (RR - 2 LR) << 8 | shift within the lane, signed; the smallest wins, i.e. the
                         // lowest SSD (LL is the same for all shifts of a pixel) and among equals the first shift
-                        const i32 gval = __mul24((i32)acc, -2) + (i32)rr[p];     // RR - 2 LR
-                        i32 key = (i32)(((u32)gval << 8) | (u32)(4 * m + i));
-                        if (4 * m + 3 >= g.q_tail) {        // uniform: the last shift-lane may hold shifts >= D
-                            if (4 * m + i >= dl) key = 0x7fffff00;   // (adding a lane's base shift below cannot wrap)
-                        }
+                        // = (RR << 8 | shift) - (LR << 9): the low 9 bits of the second term are zero, so the
+                        // shift survives in the low 8.  (Plain C on purpose: as an inline-asm v_mad_i32_i24
+                        // this read a v_dot4 result without the wait states the compiler gives its own
+                        // instructions -- wrong first rows of every tile, where no subtraction sits between.)
+                        const u32 rrk = (rr[p] << 8) | (u32)(4 * m + i);
+                        i32 key = (i32)(rrk - (acc << 9));
+                        // FULLD: the lanes' 32 shifts each are all below D (D = 32 x shift-lanes); otherwise the
+                        // last shift-lane holds shifts >= D, which must never win
+                        if (!FULLD && 4 * m + i >= dl) key = 0x7fffff00;   // (adding a lane's base shift below cannot wrap)
                         run[p] = min(run[p], key);
-                        asm volatile("" : "+v"(run[p]));
+                        asm volatile("" : : "v"(run[p]));   // (a use here: the minimum is otherwise deferred to the row's
+                                                            // end and every key kept alive until then)
                     }
                 }
                 if (OUT) {
@@ -246,10 +265,10 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
 // ---------------------------------------------------------------------------
 
 template <int N>
-static const void *ssd_ptr(int px)
+static const void *ssd_ptr(int px, bool fulld)
 {
-    if (px == 2) return (const void *)k_ssd_dot<N, 2>;
-    if (px == 4) return (const void *)k_ssd_dot<N, 4>;
+    if (px == 2) return fulld ? (const void *)k_ssd_dot<N, 2, true> : (const void *)k_ssd_dot<N, 2, false>;
+    if (px == 4) return fulld ? (const void *)k_ssd_dot<N, 4, true> : (const void *)k_ssd_dot<N, 4, false>;
     return nullptr;
 }
 
@@ -278,7 +297,7 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
     const int slots = 256 * 4 * 2;
     int best_th = 0; double best_cost = 0;
     for (int th = 8; th <= 128; th += 4) {
-        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)g.rrow;
+        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)(g.padl + g.tw + 32) * g.nl + 4 * (size_t)(g.rrow + g.rrow / 8 + 8);
         if (lds > 160 * 1024 / 8) break;
         const long long tiles = (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs;
         const long long rounds = (tiles + slots - 1) / slots;
@@ -292,15 +311,16 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
     g.nsr = g.tile_h + n - 1;
     g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0 &&
                    g.lrow + g.rrow <= 4 * 256;
-    g.lds_bytes = g.nsr * (g.lrow + g.rrow) + 4 * g.rrow;
+    g.lds_bytes = g.nsr * (g.lrow + g.rrow) + 4 * (g.padl + g.tw + 32) * g.nl + 4 * (g.rrow + g.rrow / 8 + 8);
     g.nql = nql; g.px = px;
+    const bool fulld = g.D == 4 * nql * g.nl;
     const void *fn = nullptr;
     switch (n) {
-    case 3: fn = ssd_ptr<3>(px); break;
-    case 5: fn = ssd_ptr<5>(px); break;
-    case 7: fn = ssd_ptr<7>(px); break;
-    case 9: fn = ssd_ptr<9>(px); break;
-    case 11: fn = ssd_ptr<11>(px); break;
+    case 3: fn = ssd_ptr<3>(px, fulld); break;
+    case 5: fn = ssd_ptr<5>(px, fulld); break;
+    case 7: fn = ssd_ptr<7>(px, fulld); break;
+    case 9: fn = ssd_ptr<9>(px, fulld); break;
+    case 11: fn = ssd_ptr<11>(px, fulld); break;
     }
     *out = g;
     return fn;
