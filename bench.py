@@ -53,6 +53,12 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz max clock, a wave64 VALU
 # instruction issues over 2 cycles -> wave-instructions per second, whole chip
 VALU_PEAK_GIPS = 256 * 4 * 2.4 / 2.0 * 1.0      # = 1228.8 G wave-instr/s
+# What the integer VALU of this part SUSTAINS (measured, tools/ubench_sad.hip -> profiles/r03/ubench_sad.txt,
+# launches of the match kernel's length): a stream of 15 v_bitop3 + 1 v_alignbit -- the bit-sliced kernel's
+# mix -- at the two waves per SIMD its registers allow issues 806 G wave-instr/s chip-wide (a pure v_bitop3
+# stream 869 G; more waves per SIMD lower the clock, not the time per instruction).  Reported beside the
+# datasheet-priced fraction, never instead of it.
+VALU_SUSTAINED_GIPS = 806.0
 WARMUP_FLOOR_S = 0.025          # minimum duration of the warm-up (clock ramp), see main()
 WARMUP_BURST = 16         # untimed steps right in front of the timed region (see main)
 A_CV_BYTES = 10.0               # per pixel-disparity
@@ -480,6 +486,10 @@ def main():
     if model:
         ach = model["wave_instructions"] / kernel_s / 1e9
         roof.update(achieved=round(ach, 1), frac=round(ach / VALU_PEAK_GIPS, 4),
+                    sustained_peak=VALU_SUSTAINED_GIPS, frac_of_sustained=round(ach / VALU_SUSTAINED_GIPS, 4),
+                    sustained_peak_definition="measured issue rate of the kernel's instruction mix (15 v_bitop3 : 1 "
+                                              "v_alignbit) at two waves per SIMD, profiles/r03/ubench_sad.txt; the chip "
+                                              "lowers its clock under a dense VALU stream, the datasheet peak is not reachable",
                     valu_wave_instructions_per_launch=model["wave_instructions"],
                     valu_model=model["model"], valu_model_source=model["source"])
     roof.update({

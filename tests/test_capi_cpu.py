@@ -55,6 +55,32 @@ def test_argument_validation_precedes_device_use():
     lib.sm_plan_destroy(None)  # no-op
 
 
+def test_plan_options_struct_and_argument_checks():
+    """sm_plan_create_ex: the ctypes mirror of sm_plan_options has the header's fields in the header's
+    order; a struct_size that is not one of a sm_plan_options is refused before any device work, and the
+    library reads no environment variable (variants are chosen through this struct)."""
+    import re
+    from stereomatching_amd import capi
+    text = re.sub(r"/\*.*?\*/", "", capi.HEADER.read_text(), flags=re.S)
+    body = re.search(r"typedef struct sm_plan_options \{(.*?)\} sm_plan_options;", text, re.S).group(1)
+    fields = re.findall(r"(?:int|unsigned)\s+(\w+)\s*;", body)
+    assert fields == [n for n, _ in capi.PlanOptions._fields_]
+    assert C.sizeof(capi.PlanOptions) == 4 * len(fields)
+    lib = capi.lib
+    h = C.c_void_p(0)
+    bad = capi.PlanOptions.make(tile_h=4)
+    bad.struct_size = 3
+    assert lib.sm_plan_create_ex(0, 64, 48, 30, 5, 0, 1, C.byref(bad), C.byref(h)) == capi.SM_ERR_ARG
+    assert b"struct_size" in lib.sm_last_error()
+    bad.struct_size = 4096
+    assert lib.sm_plan_create_ex(0, 64, 48, 30, 5, 0, 1, C.byref(bad), C.byref(h)) == capi.SM_ERR_ARG
+    assert lib.sm_plan_create_ex(0, 64, 48, 30, 5, 0, 1, None, None) == capi.SM_ERR_ARG
+    assert not h.value
+    csrc = ROOT / "stereomatching_amd" / "csrc"
+    for f in list(csrc.glob("*.hip")) + list(csrc.glob("*.h")):
+        assert "getenv" not in f.read_text(), f
+
+
 def test_product_package_never_touches_the_oracle():
     # the product path must not import, link or execute anything under oracle/
     pkg = ROOT / "stereomatching_amd"
