@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 : > gpurun_out/bench_all.jsonl
 for spec in "C2 1" "C4 8" "C3 1" "C3 8" "C5 1" "REF4K 1"; do
   set -- $spec
-  python3 bench.py --config $1 --pairs $2 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/bench_all.jsonl || exit 1
+  python3 bench.py --config $1 --pairs $2 --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-cost-modes 2>/dev/null | tail -1 >> gpurun_out/bench_all.jsonl || exit 1
 done
 python3 - <<'PY'
 import json
