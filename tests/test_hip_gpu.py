@@ -742,6 +742,37 @@ def test_quad_sad_unaligned_images_and_batches(hip, cost):
     plan.close()
 
 
+def test_cost_kernels_random_shapes_match_own_oracle(hip):
+    """A seeded sweep of 160 random shapes through sm_cost_wta: widths from 8 to 300 (multiples of 4 and
+    not), heights down to the window, 1 .. 300 shifts, every window 3 .. 17, both borders and costs, tile
+    heights 0 (the plan's) .. 9, images with saturated pixels -- the index arithmetic of the quad-SAD and
+    byte-dot kernels (aligned window starts, shift quads, ghost strip, ragged last tiles) against the
+    build's own CPU definition."""
+    rng = np.random.default_rng(20261004)
+    for case in range(160):
+        sw = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 4, 8]))
+        w = int(rng.integers(max(8, sw), 301))
+        if case % 3 == 0:
+            w = 4 * ((w + 3) // 4)
+        h = int(rng.integers(sw, 60))
+        d = int(rng.choice([1, 2, 3, 5, 16, 17, 30, 31, 32, 33, 63, 64, 65, 100, 128, 129, 130, 200, 256, 257, 300]))
+        mode = "ghost" if rng.integers(2) else "toroidal"
+        cost = "ssd" if rng.integers(2) else "sad"
+        th = int(rng.choice([0, 0, 1, 2, 3, 5, 9]))
+        left = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        right = np.roll(left, int(rng.integers(0, max(1, min(d, w)))), 1)
+        right = np.clip(right.astype(np.int32) + rng.integers(-3, 4, (h, w)), 0, 255).astype(np.uint8)
+        if case % 4 == 0:
+            left[rng.random((h, w)) < 0.2] = 0
+            right[rng.random((h, w)) < 0.2] = 255
+        plan = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_tile_h=th))
+        web, best = plan.cost_wta(dev(left), dev(right), cost)
+        ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, cost)
+        assert np.array_equal(host(web)[0], ow), (case, w, h, d, sw, mode, cost, th)
+        assert np.array_equal(host(best)[0], ob), (case, w, h, d, sw, mode, cost, th)
+        plan.close()
+
+
 @pytest.mark.parametrize("cfg,cost", [("C3", "sad"), ("C5", "sad"), ("C3", "ssd"), ("C5", "ssd")])
 def test_cost_mode_4k_full_image_vs_own_oracle(hip, cfg, cost):
     """The 4K configurations in the SAD / SSD cost mode (PARITY UNPINNED: the build's own CPU
