@@ -347,6 +347,9 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
     const int xe = STACKED ? (blockIdx.x * 64 + lane) * 4 : (blockIdx.x * 256 + tid) * 4;
     const int ye0 = STACKED ? (blockIdx.y * 4 + (tid >> 6)) * R : blockIdx.y * R;
     if (STACKED && ye0 >= g.ext_rows) return;             // the round-up of the strips (wave-uniform)
+    // columns no valid output pixel can reach (the match kernel's tile round-up; for the left image
+    // also the shift range): left as they are -- zero since the plan was created (wave-uniform)
+    if (((xe - 4 * lane) >> 5) >= ((blockIdx.z & 1) ? g.edge_words_r : g.edge_words_l)) return;
     const int pair = blockIdx.z >> 1, side = blockIdx.z & 1;
     const size_t img = (size_t)pair * g.w * g.h;
     const u8 *src = (side ? src_r : src_l) + img;
@@ -1061,7 +1064,7 @@ extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
     hipStream_t st = (hipStream_t)stream;
     SM_TRY(ensure_edge_tables(plan, threshold, st));
     const MatchGeom &g = plan->g;
-    const dim3 grid((g.ext_words * 32 + 255) / 256, (g.ext_rows + SM_EDGE_ROWS - 1) / SM_EDGE_ROWS,
+    const dim3 grid((g.edge_words_r * 32 + 255) / 256, (g.ext_rows + SM_EDGE_ROWS - 1) / SM_EDGE_ROWS,
                     pairs * 2), block(256);
     const bool ghost = plan->border == SM_GHOST;
     // the 4-pixels-per-lane kernel moves dwords: rows (w % 4 == 0) and base pointers
@@ -1070,7 +1073,7 @@ extern "C" int sm_find_edges(sm_plan *plan, const uint8_t *d_gray_left,
                             (uintptr_t)d_edges_left | (uintptr_t)d_edges_right) & 3) == 0;
     if (g.w % 4 == 0 && aligned4 && plan->opt.edge_kernel != 1) {
         const int strips = (g.ext_rows + SM_EDGE4_ROWS - 1) / SM_EDGE4_ROWS;
-        const int lanes = g.ext_words * 8;
+        const int lanes = g.edge_words_r * 8;       // (the left image's waves beyond its own need leave at once)
         // waves side by side, unless that rounds the row up by more than 3 % (see the kernel)
         const bool stacked = (lanes + 255) / 256 * 256 > lanes + lanes / 32;
         const dim3 grid4 = stacked ? dim3((lanes + 63) / 64, (strips + 3) / 4, pairs * 2)

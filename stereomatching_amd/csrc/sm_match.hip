@@ -505,6 +505,7 @@ int sm_match_configure(sm_plan *plan)
         g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = g.ds = 0;
         g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = g.cap2 = g.duo = 0;
         g.prio_pattern = 0;
+        g.edge_words_l = g.edge_words_r = g.ext_words;
         snprintf(plan->describe, sizeof plan->describe,
                  "generic kernel (n=%d, D=%d): 1 lane/pixel, direct window sums", g.n, D);
         return SM_OK;
@@ -690,6 +691,14 @@ int sm_match_configure(sm_plan *plan)
     }
     configure_best(ds, gsel, rws);
     g = gsel;
+#ifndef SM_EDGE_TRIM
+#define SM_EDGE_TRIM 1      // 0: edges for every ext column (same-device A/B builds)
+#endif
+    g.edge_words_l = g.edge_words_r = g.ext_words;
+    if (SM_EDGE_TRIM) {
+        g.edge_words_l = std::min(g.ext_words, (g.pad_l + W + g.half - 1) / 32 + 1);
+        g.edge_words_r = std::min(g.ext_words, (g.pad_l + W + g.half + D - 2) / 32 + 1);
+    }
     g.prio_pattern = sm_bs_default_pattern(g.duo != 0);
     if (plan->opt.priority_pattern) g.prio_pattern = plan->opt.priority_pattern;   // tuning
 
