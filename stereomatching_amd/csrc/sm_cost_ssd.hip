@@ -196,34 +196,43 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
 #pragma unroll
             for (int m = 0; m < NQ; m++) {
                 if (OUT && m + 1 < NQ) rr[PX] = sRR[r0 + (4 * (PX + m) + i) * g.nl];
+                // the PX pixels' chains side by side, group by group: a v_dot4 that accumulates onto the one
+                // issued just before it costs a wait state (three before any other reader), and the compiler
+                // pads with s_nop what the source order does not separate
+                u32 t[PX], acc[PX];
 #pragma unroll
-                for (int p = 0; p < PX; p++) {
-                    u32 t = 0;
-                    if (!WARM) {
+                for (int p = 0; p < PX; p++) { t[p] = 0; acc[p] = A[p][m][i]; }
+                if (!WARM) {
 #pragma unroll
-                        for (int gp = 0; gp < NG; gp++) t = dot4(gp == FG ? uop[p] : uo[p + gp], ro[p + m + gp], t);
-                    }
-                    u32 acc = A[p][m][i];
+                    for (int gp = 0; gp < NG; gp++)
 #pragma unroll
-                    for (int gp = 0; gp < NG; gp++) acc = dot4(gp == FG ? unp[p] : un[p + gp], rn[p + m + gp], acc);
-                    acc -= t;
-                    A[p][m][i] = acc;
-                    if (OUT) {
-                        // key: (RR - 2 LR) << 8 | shift within the lane, signed; the smallest wins, i.e. the
-                        // lowest SSD (LL is the same for all shifts of a pixel) and among equals the first shift
-                        // = (RR << 8 | shift) - (LR << 9): the low 9 bits of the second term are zero, so the
-                        // shift survives in the low 8.  (Plain C on purpose: as an inline-asm v_mad_i32_i24
-                        // this read a v_dot4 result without the wait states the compiler gives its own
-                        // instructions -- wrong first rows of every tile, where no subtraction sits between.)
+                        for (int p = 0; p < PX; p++) t[p] = dot4(gp == FG ? uop[p] : uo[p + gp], ro[p + m + gp], t[p]);
+                }
+#pragma unroll
+                for (int gp = 0; gp < NG; gp++)
+#pragma unroll
+                    for (int p = 0; p < PX; p++) acc[p] = dot4(gp == FG ? unp[p] : un[p + gp], rn[p + m + gp], acc[p]);
+#pragma unroll
+                for (int p = 0; p < PX; p++) { acc[p] -= t[p]; A[p][m][i] = acc[p]; }
+                if (OUT) {
+                    // key = (RR << 8 | shift) - (LR << 9) = (RR - 2 LR) << 8 | shift within the lane, signed: the
+                    // smallest wins, i.e. the lowest SSD (LL is the same for all shifts of a pixel) and among
+                    // equals the first shift.  (Plain C on purpose: as an inline-asm v_mad_i32_i24 this read a
+                    // v_dot4 result without the wait states the compiler gives its own instructions -- wrong
+                    // first rows of every tile, where no subtraction sits between.)
+#pragma unroll
+                    for (int p = 0; p < PX; p++) {
                         const u32 rrk = (rr[p] << 8) | (u32)(4 * m + i);
-                        i32 key = (i32)(rrk - (acc << 9));
+                        i32 key = (i32)(rrk - (acc[p] << 9));
                         // FULLD: the lanes' 32 shifts each are all below D (D = 32 x shift-lanes); otherwise the
                         // last shift-lane holds shifts >= D, which must never win
                         if (!FULLD && 4 * m + i >= dl) key = 0x7fffff00;   // (adding a lane's base shift below cannot wrap)
                         run[p] = min(run[p], key);
-                        asm volatile("" : : "v"(run[p]));   // (a use here: the minimum is otherwise deferred to the row's
-                                                            // end and every key kept alive until then)
                     }
+#pragma unroll
+                    for (int p = 0; p < PX; p++)
+                        asm volatile("" : : "v"(run[p]));   // (a use here: the minima are otherwise deferred to the
+                                                            // row's end and every key kept alive until then)
                 }
                 if (OUT) {
 #pragma unroll
