@@ -8,7 +8,7 @@
 // not per shift -- and LR_d the window sum of the products, the only per-shift work:
 //     t  = dot4(left group, right group of the row that slides out, ...)       NG = ceil(n/4) x v_dot4_u32_u8
 //     LR = dot4(left group, right group of the row that slides in, LR) - t     NG + 1
-//     key = (RR[x + d] << 8 | shift) - (LR << 9)     = (RR - 2 LR) << 8 | shift; signed first-wins minimum
+//     -key = (LR << 9) - (RR[x + d] << 8) - shift    key = (RR - 2 LR) << 8 | shift: signed, first shift wins
 // The last group of a window row holds n mod 4 pixels: the other bytes of the LEFT operand are
 // zeroed and their products vanish -- no correction term (as the SAD kernel needs) exists here.
 //
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
 
         i32 run[PX];
 #pragma unroll
-        for (int p = 0; p < PX; p++) run[p] = 0x7fffff00;
+        for (int p = 0; p < PX; p++) run[p] = (i32)0x80000100;      // -(0x7fffff00): "nothing yet", loses to every key
         int dl = dlim;                      // (opaque: keeps the per-lane validity tests inside the row loop)
         asm volatile("" : "+v"(dl));
 
@@ -187,15 +187,15 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                 if (!WARM) ro[k] = i ? __builtin_amdgcn_alignbyte(wo[k + 1], wo[k], i) : wo[k];
             }
             // RR of (pixel p, shift 4 m + i) is entry r0 + 4 (p + m) + i: a window of PX entries slides over m
-            u32 rr[PX + 1];
+            u32 nrr[PX + 1];            // -(RR << 8) of the window's entries
             if (OUT) {
 #pragma unroll
-                for (int p = 0; p < PX; p++) rr[p] = sRR[r0 + (4 * p + i) * g.nl];
+                for (int p = 0; p < PX; p++) nrr[p] = 0u - (sRR[r0 + (4 * p + i) * g.nl] << 8);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < NQ; m++) {
-                if (OUT && m + 1 < NQ) rr[PX] = sRR[r0 + (4 * (PX + m) + i) * g.nl];
+                if (OUT && m + 1 < NQ) nrr[PX] = 0u - (sRR[r0 + (4 * (PX + m) + i) * g.nl] << 8);
                 // the PX pixels' chains side by side, group by group: a v_dot4 that accumulates onto the one
                 // issued just before it costs a wait state (three before any other reader), and the compiler
                 // pads with s_nop what the source order does not separate
@@ -215,28 +215,28 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
 #pragma unroll
                 for (int p = 0; p < PX; p++) { acc[p] -= t[p]; A[p][m][i] = acc[p]; }
                 if (OUT) {
-                    // key = (RR << 8 | shift) - (LR << 9) = (RR - 2 LR) << 8 | shift within the lane, signed: the
-                    // smallest wins, i.e. the lowest SSD (LL is the same for all shifts of a pixel) and among
-                    // equals the first shift.  (Plain C on purpose: as an inline-asm v_mad_i32_i24 this read a
-                    // v_dot4 result without the wait states the compiler gives its own instructions -- wrong
-                    // first rows of every tile, where no subtraction sits between.)
+                    // key = (RR - 2 LR) << 8 | shift within the lane, signed: the smallest wins, i.e. the lowest
+                    // SSD (LL is the same for all shifts of a pixel) and among equals the first shift.  Formed
+                    // NEGATED, -key = (LR << 9) + (-(RR << 8) - shift), one v_lshl_add_u32 behind one subtract of a
+                    // constant from the (negated, pre-shifted) RR entry, and the MAXIMUM is kept.  (Plain C on
+                    // purpose: as an inline-asm v_mad_i32_i24 this read a v_dot4 result without the wait states
+                    // the compiler gives its own instructions -- wrong first rows of every tile.)
 #pragma unroll
                     for (int p = 0; p < PX; p++) {
-                        const u32 rrk = (rr[p] << 8) | (u32)(4 * m + i);
-                        i32 key = (i32)(rrk - (acc[p] << 9));
+                        i32 nkey = (i32)((acc[p] << 9) + (nrr[p] - (u32)(4 * m + i)));
                         // FULLD: the lanes' 32 shifts each are all below D (D = 32 x shift-lanes); otherwise the
                         // last shift-lane holds shifts >= D, which must never win
-                        if (!FULLD && 4 * m + i >= dl) key = 0x7fffff00;   // (adding a lane's base shift below cannot wrap)
-                        run[p] = min(run[p], key);
+                        if (!FULLD && 4 * m + i >= dl) nkey = (i32)0x80000100;
+                        run[p] = max(run[p], nkey);
                     }
 #pragma unroll
                     for (int p = 0; p < PX; p++)
-                        asm volatile("" : : "v"(run[p]));   // (a use here: the minima are otherwise deferred to the
+                        asm volatile("" : : "v"(run[p]));   // (a use here: the maxima are otherwise deferred to the
                                                             // row's end and every key kept alive until then)
                 }
                 if (OUT) {
 #pragma unroll
-                    for (int p = 0; p < PX; p++) rr[p] = rr[p + 1];
+                    for (int p = 0; p < PX; p++) nrr[p] = nrr[p + 1];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
         if (OUT) {
 #pragma unroll
             for (int p = 0; p < PX; p++) {
-                i32 key = run[p] + 4 * NQ * sl;             // the low 8 bits become the shift itself
+                i32 key = 4 * NQ * sl - run[p];             // back to the key; its low 8 bits become the shift itself
                 for (int k = 0; k < g.log2nl; k++) key = min(key, __shfl_xor(key, 4 << k));
                 const int x = x0 + 4 * p;
                 if (sl == 0 && x < g.w) {
