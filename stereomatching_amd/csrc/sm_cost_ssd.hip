@@ -58,12 +58,13 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
     // the lanes of a wave (which differ by multiples of 32 positions) read 32 different banks and a
     // lane's entries are a constant stride apart (the plain [position] table cost 8-way conflicts:
     // 178 M conflict cycles against 35 M LDS cycles at C5)
-    u32 *sRR = sR + g.nsr * rw;
-    u32 *sD = sRR + (g.padl + g.tw + 32) * g.nl;                     // [rrow, skewed]: this row step's differences by position
+    u32 *sRR = lds + ((g.nsr * (lw + rw) + 3) & ~3);                 // (16-byte aligned: read and written as quads)
+    u32 *sD = sRR + (((g.padl + g.tw + 32) * g.nl + 3) & ~3);        // [positions, skewed]: this row step's differences
 
     smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid);
     const int nloc = g.padl + g.tw + 32;
-    for (int r = tid; r < nloc * g.nl; r += 64) sRR[r] = 0;
+    for (int r = tid; r < ((nloc * g.nl + 3) & ~3); r += 64) sRR[r] = 0;
+    for (int r = tid; r < g.rrow + g.rrow / 8 + 8; r += 64) sD[r] = 0;   // (positions phase 1 does not reach read as 0)
     __syncthreads();
 
     // ---- lane role: residue a, shift-lane sl, pixel group j
@@ -99,28 +100,72 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
         // flat row (skewed by 4 words per 32 positions), then every table entry (l, s) adds the one of
         // position l + 32 s -- consecutive lanes, consecutive entries.  (Updating the interleaved table by
         // position instead put 8 lanes on each bank: 99 M conflict cycles against 46 M LDS cycles at C5.)
-        for (int q = tid + HALF; q < g.rrow - HALF - 4; q += 64) {
-            const int b0 = q - HALF, wq = b0 >> 2, sh = b0 & 3;
-            u32 sn = 0, so = 0;
+        // A lane takes FOUR consecutive positions / entries per turn and all reads of its turns are issued
+        // before the first use: written one position and one entry at a time, with a load - wait - store
+        // chain per turn (5 + 13 turns a row), this update was a fifth of the kernel's time.
+#ifndef SSD_EXPERIMENT_NO_RR     // (timing experiment only: how much of a row is the RR update)
+        {
+            constexpr int T1 = 2;                       // turns of phase 1: rrow <= 4 * 64 * T1 (checked by the host)
+            u32 rn_[T1][NG + 2], ro_[T1][NG + 2];
 #pragma unroll
-            for (int gp = 0; gp < NG; gp++) {
-                u32 v = __builtin_amdgcn_alignbyte(rowRn[wq + gp + 1], rowRn[wq + gp], sh);
-                if (gp == FG) v &= MASKR;
-                sn = dot4(v, v, sn);
-                if (!WARM) {
-                    u32 u = __builtin_amdgcn_alignbyte(rowRo[wq + gp + 1], rowRo[wq + gp], sh);
-                    if (gp == FG) u &= MASKR;
-                    so = dot4(u, u, so);
+            for (int it = 0; it < T1; it++) {
+                const int k = min(tid + 64 * it, rw - NG - 2);      // (a clamped turn repeats the last one: same values)
+#pragma unroll
+                for (int c = 0; c < NG + 2; c++) {
+                    rn_[it][c] = rowRn[k + c];
+                    if (!WARM) ro_[it][c] = rowRo[k + c];
                 }
             }
-            sD[q + 4 * (q >> 5)] = sn - so;
+#pragma unroll
+            for (int it = 0; it < T1; it++) {
+                const int k = min(tid + 64 * it, rw - NG - 2);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {           // position q = 4 k + HALF + i: its window starts at byte 4 k + i
+                    u32 sn = 0, so = 0;
+#pragma unroll
+                    for (int gp = 0; gp < NG; gp++) {
+                        u32 v = i ? __builtin_amdgcn_alignbyte(rn_[it][gp + 1], rn_[it][gp], i) : rn_[it][gp];
+                        if (gp == FG) v &= MASKR;
+                        sn = dot4(v, v, sn);
+                        if (!WARM) {
+                            u32 u = i ? __builtin_amdgcn_alignbyte(ro_[it][gp + 1], ro_[it][gp], i) : ro_[it][gp];
+                            if (gp == FG) u &= MASKR;
+                            so = dot4(u, u, so);
+                        }
+                    }
+                    const int q = 4 * k + HALF + i;
+                    sD[q + 4 * (q >> 5)] = sn - so;
+                }
+            }
         }
         __syncthreads();
-        for (int e = tid; e < nloc * g.nl; e += 64) {
-            const int q = (e >> g.log2nl) + 32 * (e & (g.nl - 1));
-            if (q >= HALF && q < g.rrow - HALF - 4) sRR[e] += sD[q + 4 * (q >> 5)];
+        {
+            constexpr int T2 = 3;                       // turns of phase 2: entries <= 4 * 64 * T2 (checked by the host)
+            const int n4 = (nloc * g.nl + 3) >> 2;      // (the table is padded to whole quads)
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            v4u *sRR4 = reinterpret_cast<v4u *>(sRR);
+            v4u cur[T2], dv[T2];
+#pragma unroll
+            for (int it = 0; it < T2; it++) {
+                const int e4 = tid + 64 * it;
+                if (e4 < n4) {                          // uniform per wave except in the last turn
+                    cur[it] = sRR4[e4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int e = 4 * e4 + c;
+                        const int q = (e >> g.log2nl) + 32 * (e & (g.nl - 1));
+                        dv[it][c] = sD[q + 4 * (q >> 5)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < T2; it++) {
+                const int e4 = tid + 64 * it;
+                if (e4 < n4) sRR4[e4] = cur[it] + dv[it];
+            }
         }
         __syncthreads();
+#endif
 
         // left operands of this lane's PX windows: NG groups each, 4 pixels apart -> NG + PX - 1 dwords
         u32 un[WL], unp[PX], uo[WL], uop[PX];
@@ -306,7 +351,8 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
     const int slots = 256 * 4 * 2;
     int best_th = 0; double best_cost = 0;
     for (int th = 8; th <= 128; th += 4) {
-        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)(g.padl + g.tw + 32) * g.nl + 4 * (size_t)(g.rrow + g.rrow / 8 + 8);
+        const size_t lds = (((size_t)(th + n - 1) * (g.lrow + g.rrow) + 15) & ~(size_t)15) +
+                           4 * (size_t)(((g.padl + g.tw + 32) * g.nl + 3) & ~3) + 4 * (size_t)(g.rrow + g.rrow / 8 + 8);
         if (lds > 160 * 1024 / 8) break;
         const long long tiles = (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs;
         const long long rounds = (tiles + slots - 1) / slots;
@@ -320,7 +366,10 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
     g.nsr = g.tile_h + n - 1;
     g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0 &&
                    g.lrow + g.rrow <= 4 * 256;
-    g.lds_bytes = g.nsr * (g.lrow + g.rrow) + 4 * (g.padl + g.tw + 32) * g.nl + 4 * (g.rrow + g.rrow / 8 + 8);
+    g.lds_bytes = ((g.nsr * (g.lrow + g.rrow) + 15) & ~15) + 4 * (((g.padl + g.tw + 32) * g.nl + 3) & ~3) +
+                  4 * (g.rrow + g.rrow / 8 + 8);
+    // the RR update's fixed number of turns (k_ssd_dot: T1, T2)
+    if (g.rrow > 4 * 64 * 2 || (g.padl + g.tw + 32) * g.nl > 4 * 64 * 3) return nullptr;
     g.nql = nql; g.px = px;
     const bool fulld = g.D == 4 * nql * g.nl;
     const void *fn = nullptr;

@@ -44,6 +44,7 @@ for name_, so, envs in entries:
     lib.sm_last_error.restype = C.c_char_p
     lib.sm_find_edges.argtypes = [vp, vp, vp, C.c_double, C.c_int, vp, vp, vp]
     lib.sm_match_wta.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.sm_cost_wta.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     plan = vp()
     opts = struct_from_spec(envs)          # (variants are chosen through sm_plan_create_ex, not the environment)
     assert lib.sm_plan_create_ex(0, w, h, d, sw, 1 if mode == "ghost" else 0, pairs, C.byref(opts), C.byref(plan)) == 0
@@ -67,7 +68,10 @@ for r in range(rounds + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            if os.environ.get("AB_STEP"):      # the whole step: edges, then match
+            if os.environ.get("AB_COST"):      # the cost mode (sad / ssd) on the gray images
+                assert lib.sm_cost_wta(plan, L.data_ptr(), R.data_ptr(), 1 if os.environ["AB_COST"] == "sad" else 2,
+                                       pairs, web.data_ptr(), None, None) == 0
+            elif os.environ.get("AB_STEP"):    # the whole step: edges, then match
                 assert lib.sm_find_edges(plan, L.data_ptr(), R.data_ptr(), 0.15, pairs, None, None, None) == 0
                 assert lib.sm_match_wta(plan, pairs, web.data_ptr(), None, None) == 0
             elif os.environ.get("AB_EDGES"):
