@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
         const u32 *rowLo = sL + ro_i * lw, *rowRo = sR + ro_i * rw;
 
         // E: per right dword position, (bytes the zeroed left bytes pick up in the new row) - (old row)
+#ifndef SAD_EXPERIMENT_NO_E      // (timing experiment only: what the E update and its barrier cost per row)
         for (int k = tid; k < rw - 1; k += 64) {
             const u64 mn = __builtin_amdgcn_mqsad_pk_u16_u8(ld_pair(rowRn, k), MASKC, 0ull);   // 255 (4-RB) - T_new
             u64 e;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
             sE[k] = e;
         }
         __syncthreads();
+#endif
 
         // left operands of this lane's PX windows: NG groups each, 4 pixels apart -> NG + PX - 1 dwords
         u32 un[WN], unp[PX], uo[WN], uop[PX];

@@ -53,18 +53,16 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
     const int lw = g.lrow >> 2, rw = g.rrow >> 2;                    // dwords per staged row
     u32 *sL = lds;                                                   // [nsr][lw]
     u32 *sR = sL + g.nsr * lw;                                       // [nsr][rw]
-    // RR of the current output row, [nloc][nl]: entry (l, sl) is the window sum of squares centred on
-    // right byte position l + 32 sl of the staged row -- one copy per shift-lane, interleaved, so that
-    // the lanes of a wave (which differ by multiples of 32 positions) read 32 different banks and a
-    // lane's entries are a constant stride apart (the plain [position] table cost 8-way conflicts:
-    // 178 M conflict cycles against 35 M LDS cycles at C5)
-    u32 *sRR = lds + ((g.nsr * (lw + rw) + 3) & ~3);                 // (16-byte aligned: read and written as quads)
-    u32 *sD = sRR + (((g.padl + g.tw + 32) * g.nl + 3) & ~3);        // [positions, skewed]: this row step's differences
+    // RR of the current output row by right byte position (the window centre), flat.  The lanes of a wave
+    // that differ in their shift-lane read entries 32 apart -- the same bank: 8-way conflicts on the 44
+    // reads of a lane and row at 256 shifts.  An interleaved [position][shift-lane] table removes them
+    // (178 M -> 21 M conflict cycles at C5) and was measured SLOWER, 1.32 vs 1.22 ms: keeping it
+    // up to date takes 3 600 LDS cycles per wave and row (quad writes are 13 cycles each) against the
+    // 700 the conflicts cost, in four dependent LDS round trips (profiles/r03/ab_ssd_rr_phase.txt).
+    u32 *sRR = sR + g.nsr * rw;                                      // [rrow]
 
     smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid);
-    const int nloc = g.padl + g.tw + 32;
-    for (int r = tid; r < ((nloc * g.nl + 3) & ~3); r += 64) sRR[r] = 0;
-    for (int r = tid; r < g.rrow + g.rrow / 8 + 8; r += 64) sD[r] = 0;   // (positions phase 1 does not reach read as 0)
+    for (int r = tid; r < g.rrow; r += 64) sRR[r] = 0;
     __syncthreads();
 
     // ---- lane role: residue a, shift-lane sl, pixel group j
@@ -75,7 +73,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
     const int rho = (a - HALF) & 3;                     // (x - HALF) mod 4
     const int bL = (x0 - HALF - rho - (xw - g.padl)) >> 2;      // dword of the window's aligned start
     const int bR = bL + NQ * sl;                        // ... of the lane's first shift (32 sl)
-    const int r0 = (x0 - (xw - g.padl)) * g.nl + sl;    // RR entry of (pixel 0, shift 32 sl); one position further: + nl
+    const int r0 = x0 - (xw - g.padl) + 4 * NQ * sl;    // RR entry of (pixel 0, shift 32 sl)
     const int dlim = g.D - 4 * NQ * sl;                 // this lane's shifts below D
 
     u32 A[PX][NQ][4];            // LR window sums of (pixel, quad, shift within the quad)
@@ -96,72 +94,31 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
         const u32 *rowLo = sL + ro_i * lw, *rowRo = sR + ro_i * rw;
 
         // RR: per right byte position q (the window centre), + the new row's horizontal sum of squares
-        // - the old row's.  Two phases, both free of bank conflicts: the differences by position into a
-        // flat row (skewed by 4 words per 32 positions), then every table entry (l, s) adds the one of
-        // position l + 32 s -- consecutive lanes, consecutive entries.  (Updating the interleaved table by
-        // position instead put 8 lanes on each bank: 99 M conflict cycles against 46 M LDS cycles at C5.)
-        // A lane takes FOUR consecutive positions / entries per turn and all reads of its turns are issued
-        // before the first use: written one position and one entry at a time, with a load - wait - store
-        // chain per turn (5 + 13 turns a row), this update was a fifth of the kernel's time.
+        // - the old row's; a lane takes four consecutive positions a turn (their windows are the four
+        // byte alignments of the same dwords).  Positions whose window leaves the staged row are never read.
 #ifndef SSD_EXPERIMENT_NO_RR     // (timing experiment only: how much of a row is the RR update)
-        {
-            constexpr int T1 = 2;                       // turns of phase 1: rrow <= 4 * 64 * T1 (checked by the host)
-            u32 rn_[T1][NG + 2], ro_[T1][NG + 2];
+        for (int k = tid; k <= rw - NG - 2; k += 64) {
+            u32 rn_[NG + 2], ro_[NG + 2];
 #pragma unroll
-            for (int it = 0; it < T1; it++) {
-                const int k = min(tid + 64 * it, rw - NG - 2);      // (a clamped turn repeats the last one: same values)
-#pragma unroll
-                for (int c = 0; c < NG + 2; c++) {
-                    rn_[it][c] = rowRn[k + c];
-                    if (!WARM) ro_[it][c] = rowRo[k + c];
-                }
+            for (int c = 0; c < NG + 2; c++) {
+                rn_[c] = rowRn[k + c];
+                if (!WARM) ro_[c] = rowRo[k + c];
             }
 #pragma unroll
-            for (int it = 0; it < T1; it++) {
-                const int k = min(tid + 64 * it, rw - NG - 2);
+            for (int i = 0; i < 4; i++) {               // position q = 4 k + HALF + i: its window starts at byte 4 k + i
+                u32 sn = 0, so = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {           // position q = 4 k + HALF + i: its window starts at byte 4 k + i
-                    u32 sn = 0, so = 0;
-#pragma unroll
-                    for (int gp = 0; gp < NG; gp++) {
-                        u32 v = i ? __builtin_amdgcn_alignbyte(rn_[it][gp + 1], rn_[it][gp], i) : rn_[it][gp];
-                        if (gp == FG) v &= MASKR;
-                        sn = dot4(v, v, sn);
-                        if (!WARM) {
-                            u32 u = i ? __builtin_amdgcn_alignbyte(ro_[it][gp + 1], ro_[it][gp], i) : ro_[it][gp];
-                            if (gp == FG) u &= MASKR;
-                            so = dot4(u, u, so);
-                        }
-                    }
-                    const int q = 4 * k + HALF + i;
-                    sD[q + 4 * (q >> 5)] = sn - so;
-                }
-            }
-        }
-        __syncthreads();
-        {
-            constexpr int T2 = 3;                       // turns of phase 2: entries <= 4 * 64 * T2 (checked by the host)
-            const int n4 = (nloc * g.nl + 3) >> 2;      // (the table is padded to whole quads)
-            typedef u32 v4u __attribute__((ext_vector_type(4)));
-            v4u *sRR4 = reinterpret_cast<v4u *>(sRR);
-            v4u cur[T2], dv[T2];
-#pragma unroll
-            for (int it = 0; it < T2; it++) {
-                const int e4 = tid + 64 * it;
-                if (e4 < n4) {                          // uniform per wave except in the last turn
-                    cur[it] = sRR4[e4];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const int e = 4 * e4 + c;
-                        const int q = (e >> g.log2nl) + 32 * (e & (g.nl - 1));
-                        dv[it][c] = sD[q + 4 * (q >> 5)];
+                for (int gp = 0; gp < NG; gp++) {
+                    u32 v = i ? __builtin_amdgcn_alignbyte(rn_[gp + 1], rn_[gp], i) : rn_[gp];
+                    if (gp == FG) v &= MASKR;
+                    sn = dot4(v, v, sn);
+                    if (!WARM) {
+                        u32 u = i ? __builtin_amdgcn_alignbyte(ro_[gp + 1], ro_[gp], i) : ro_[gp];
+                        if (gp == FG) u &= MASKR;
+                        so = dot4(u, u, so);
                     }
                 }
-            }
-#pragma unroll
-            for (int it = 0; it < T2; it++) {
-                const int e4 = tid + 64 * it;
-                if (e4 < n4) sRR4[e4] = cur[it] + dv[it];
+                sRR[4 * k + HALF + i] += sn - so;
             }
         }
         __syncthreads();
@@ -235,12 +192,12 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
             u32 nrr[PX + 1];            // -(RR << 8) of the window's entries
             if (OUT) {
 #pragma unroll
-                for (int p = 0; p < PX; p++) nrr[p] = 0u - (sRR[r0 + (4 * p + i) * g.nl] << 8);
+                for (int p = 0; p < PX; p++) nrr[p] = 0u - (sRR[r0 + 4 * p + i] << 8);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < NQ; m++) {
-                if (OUT && m + 1 < NQ) nrr[PX] = 0u - (sRR[r0 + (4 * (PX + m) + i) * g.nl] << 8);
+                if (OUT && m + 1 < NQ) nrr[PX] = 0u - (sRR[r0 + 4 * (PX + m) + i] << 8);
                 // the PX pixels' chains side by side, group by group: a v_dot4 that accumulates onto the one
                 // issued just before it costs a wait state (three before any other reader), and the compiler
                 // pads with s_nop what the source order does not separate
@@ -351,8 +308,7 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
     const int slots = 256 * 4 * 2;
     int best_th = 0; double best_cost = 0;
     for (int th = 8; th <= 128; th += 4) {
-        const size_t lds = (((size_t)(th + n - 1) * (g.lrow + g.rrow) + 15) & ~(size_t)15) +
-                           4 * (size_t)(((g.padl + g.tw + 32) * g.nl + 3) & ~3) + 4 * (size_t)(g.rrow + g.rrow / 8 + 8);
+        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)g.rrow;
         if (lds > 160 * 1024 / 8) break;
         const long long tiles = (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs;
         const long long rounds = (tiles + slots - 1) / slots;
@@ -366,10 +322,7 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
     g.nsr = g.tile_h + n - 1;
     g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0 &&
                    g.lrow + g.rrow <= 4 * 256;
-    g.lds_bytes = ((g.nsr * (g.lrow + g.rrow) + 15) & ~15) + 4 * (((g.padl + g.tw + 32) * g.nl + 3) & ~3) +
-                  4 * (g.rrow + g.rrow / 8 + 8);
-    // the RR update's fixed number of turns (k_ssd_dot: T1, T2)
-    if (g.rrow > 4 * 64 * 2 || (g.padl + g.tw + 32) * g.nl > 4 * 64 * 3) return nullptr;
+    g.lds_bytes = g.nsr * (g.lrow + g.rrow) + 4 * g.rrow;
     g.nql = nql; g.px = px;
     const bool fulld = g.D == 4 * nql * g.nl;
     const void *fn = nullptr;
