@@ -67,8 +67,12 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
 
     // ---- lane role: residue a, shift-lane sl, pixel group j
     const int a = tid & 3;
-    const int sl = (tid >> 2) & (g.nl - 1);
-    const int j = tid >> (2 + g.log2nl);
+    // lane = a | j0 << 2 | sl << 3 | (rest of j): one bit of the pixel group sits BELOW the shift-lane
+    // (where a wave holds two groups or more), so that a half-wave -- the unit LDS conflicts are counted in --
+    // holds half as many shift-lanes: their RR reads are 32 entries apart, the same bank
+    const int jb = g.nl < 16 ? 1 : 0;                   // 16 / nl pixel groups per wave
+    const int sl = (tid >> (2 + jb)) & (g.nl - 1);
+    const int j = ((tid >> 2) & jb) | ((tid >> (2 + jb + g.log2nl)) << jb);
     const int x0 = xw + 4 * PX * j + a;                 // pixel p of this lane: x0 + 4 p
     const int rho = (a - HALF) & 3;                     // (x - HALF) mod 4
     const int bL = (x0 - HALF - rho - (xw - g.padl)) >> 2;      // dword of the window's aligned start
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
 #pragma unroll
             for (int p = 0; p < PX; p++) {
                 i32 key = 4 * NQ * sl - run[p];             // back to the key; its low 8 bits become the shift itself
-                for (int k = 0; k < g.log2nl; k++) key = min(key, __shfl_xor(key, 4 << k));
+                for (int k = 0; k < g.log2nl; k++) key = min(key, __shfl_xor(key, (4 << jb) << k));
                 const int x = x0 + 4 * p;
                 if (sl == 0 && x < g.w) {
                     const size_t o = ((size_t)pair * g.h + y) * g.w + x;
