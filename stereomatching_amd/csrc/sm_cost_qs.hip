@@ -287,7 +287,7 @@ const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_le
     g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
     const int half = plan->square_width / 2, n = 2 * half + 1;
     g.ghost = plan->border == SM_GHOST;
-    if (n < 3 || n > 15 || g.D > 4 * 4 * 33 - 3 || plan->opt.cost_kernel == 1) return nullptr;
+    if (n < 3 || n > 15 || g.D > 512 || plan->opt.cost_kernel == 1) return nullptr;     // (512: the entry's own limit)
     const int nq = (g.D + 3 + 3) / 4;               // quads that cover shifts -3 .. D-1
     int nql, px;
     if (nq <= 5) { nql = 5; px = 4; }
