@@ -80,8 +80,11 @@ def parse(argv=None):
     ap.add_argument("--no-cost-modes", action="store_true", help="skip the extra `sad` / `ssd` objects (N = 1)")
     ap.add_argument("--cpu-rows", type=int, default=192, help="rows of the CPU-baseline band")
     ap.add_argument("--pipeline", action="store_true",
-                    help="overlap the edge kernel of step i+1 with the match kernel of step i "
-                         "(sm_plan_set_pipelined; measured: no net gain, both kernels are VALU-heavy)")
+                    help="let consecutive steps overlap on the plan's two internal lanes (sm_plan_set_pipelined: "
+                         "edges of step i+1 beside the match of step i, the head of match i+1 in the tail of match i; "
+                         "measured +1.4 %% at C3, profiles/r03/ab_pipelined_lanes.txt).  Off by default: a step is "
+                         "then no longer one serial pass, and the per-launch kernel time is that of launches "
+                         "sharing the chip")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region, collect the maps on rank 0 over RCCL and time it")
     ap.add_argument("--no-e2e", action="store_true",
@@ -380,8 +383,7 @@ def main():
     turn = [0]
 
     # Optional: the inputs are resident and complete, so consecutive steps may overlap
-    # (edge kernel of step i+1 beside the match kernel of step i on the plan's internal
-    # stream).  Every step still does all its work.
+    # (step i on the plan's internal lane i & 1).  Every step still does all its work.
     plan.set_pipelined(args.pipeline)
     plan.prepare_threshold(args.threshold)     # set-up next to the allocations
 

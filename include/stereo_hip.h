@@ -192,16 +192,25 @@ int sm_match_wta(sm_plan *plan, int pairs, int32_t *d_web, int32_t *d_best,
 int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web, int web_type,
                        int32_t *d_best, void *stream);
 
-/* Let consecutive sm_run calls overlap: with the flag set, sm_run launches its
- * edge detection on an internal stream into the other half of a double-buffered
- * workspace, so that it runs beside the (VALU-bound) match kernel of the
- * PREVIOUS call; the match kernel itself still goes to `stream`, and
- * synchronising `stream` still means "all results are there".  The caller
- * promises that the input images handed to sm_run are complete in memory when
- * sm_run is called (it no longer orders them behind earlier work on `stream`);
- * enabled = 2 keeps that ordering too (one more event per call): use it when the
- * inputs are uploaded asynchronously on `stream` just before sm_run.
- * Off by default.                                                             */
+/* Let consecutive sm_run calls overlap.  With the flag set, call i runs on one of two
+ * internal streams ("lanes", i & 1), edge detection and match launch in order, into the
+ * lane's own half of a double-buffered workspace; nothing orders the lanes against each
+ * other, so the edge detection of call i + 1 runs beside the match kernel of call i and
+ * the first waves of match i + 1 take the SIMD slots the early finishers of match i
+ * leave.  `stream` waits for the call's release event: synchronising `stream` still
+ * means "all results are there", and work put on `stream` after the call sees them.
+ * Two consecutive calls that share anything -- overlapping result maps, a changed
+ * threshold (the decision tables are rebuilt), the staging map of a narrow result from
+ * a fallback kernel -- are put in order by the library; give consecutive calls their
+ * own result maps to get the overlap.  At most two calls are in flight.  The caller
+ * promises that, when sm_run is called, the input images are complete in memory and no
+ * work of its own that is still pending (on `stream` or elsewhere) reads or writes the
+ * result maps it hands over: the call is no longer ordered behind earlier work on
+ * `stream`, only behind earlier sm_run calls.  enabled = 2 keeps that ordering too (one
+ * more event per call, and no overlap with the call before, whose results `stream`
+ * waits for): use it when the inputs are uploaded asynchronously on `stream` just
+ * before sm_run.  sm_plan_kernel_ms then measures launches that share the chip with
+ * their neighbours: longer each, shorter together.  Off by default.                  */
 int sm_plan_set_pipelined(sm_plan *plan, int enabled);
 
 /* Measurement aid: with capacity > 0 the plan brackets each of the next

@@ -863,11 +863,8 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
     hipError_t e = hipMalloc((void **)&p->d_ext_buf[0], p->ext_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_ext_buf[1], p->ext_bytes);
     if (e == hipSuccess) e = hipMemset(p->d_ext_buf[1], 0, p->ext_bytes);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->edge_stream, hipStreamNonBlocking);
-    for (int b = 0; b < 2 && e == hipSuccess; b++) {
-        e = hipEventCreateWithFlags(&p->ev_edges[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_free[b], hipEventDisableTiming);
-    }
+    for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipStreamCreateWithFlags(&p->lane[b], hipStreamNonBlocking);
+    for (int q = 0; q < 4 && e == hipSuccess; q++) e = hipEventCreateWithFlags(&p->ev_free[q], hipEventDisableTiming);
     p->d_ext = p->d_ext_buf[0];
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_inputs, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flags, 4 * sizeof(i32));
@@ -882,10 +879,10 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
     if (e != hipSuccess) {
         for (int b = 0; b < 2; b++) {
             if (p->d_ext_buf[b]) (void)hipFree(p->d_ext_buf[b]);
-            if (p->ev_edges[b]) (void)hipEventDestroy(p->ev_edges[b]);
-            if (p->ev_free[b]) (void)hipEventDestroy(p->ev_free[b]);
+            if (p->lane[b]) (void)hipStreamDestroy(p->lane[b]);
         }
-        if (p->edge_stream) (void)hipStreamDestroy(p->edge_stream);
+        for (int q = 0; q < 4; q++)
+            if (p->ev_free[q]) (void)hipEventDestroy(p->ev_free[q]);
         if (p->ev_inputs) (void)hipEventDestroy(p->ev_inputs);
         if (p->d_flags) (void)hipFree(p->d_flags);
         if (p->d_edge_tab) (void)hipFree(p->d_edge_tab);
@@ -922,14 +919,13 @@ extern "C" void sm_plan_destroy(sm_plan *plan)
 {
     if (!plan) return;
     (void)hipSetDevice(plan->device);
-    (void)hipStreamSynchronize(plan->edge_stream);
+    for (int b = 0; b < 2; b++) (void)hipStreamSynchronize(plan->lane[b]);
     free_timing(plan);
     for (int b = 0; b < 2; b++) {
         (void)hipFree(plan->d_ext_buf[b]);
-        (void)hipEventDestroy(plan->ev_edges[b]);
-        (void)hipEventDestroy(plan->ev_free[b]);
+        (void)hipStreamDestroy(plan->lane[b]);
     }
-    (void)hipStreamDestroy(plan->edge_stream);
+    for (int q = 0; q < 4; q++) (void)hipEventDestroy(plan->ev_free[q]);
     (void)hipEventDestroy(plan->ev_inputs);
     if (plan->d_web_tmp) (void)hipFree(plan->d_web_tmp);
     (void)hipFree(plan->d_flags);
@@ -1185,11 +1181,11 @@ extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int
     if (timed && !attach) SM_HIP(hipEventRecord(plan->t_end[plan->timing_n], (hipStream_t)stream));
     if (timed) plan->timing_n++;
     if (plan->pipelined) {
-        // the next-but-one sm_run must not overwrite this buffer before the launch has read it
-        SM_HIP(hipEventRecord(plan->ev_free[plan->cur], (hipStream_t)stream));
-        plan->ev_free_set[plan->cur] = 1;
+        // the release event of pipelined call number seq: `stream` of sm_run waits for it, and so do
+        // later calls that must not overtake this one
+        SM_HIP(hipEventRecord(plan->ev_free[plan->seq & 3], (hipStream_t)stream));
+        plan->ev_free_set[plan->seq & 3] = 1;
     } else {
-        plan->ev_free_set[plan->cur] = 0;
         plan->unfenced = 1;                // launches a later pipelined phase has no event for
     }
     return SM_OK;
@@ -1272,31 +1268,48 @@ extern "C" int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uin
         SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, stream));
         return sm_match_wta_typed(plan, pairs, d_web, web_type, d_best, stream);
     }
-    // pipelined: edges of this call on the internal stream, into the buffer the
-    // previous call's match is NOT reading
+    // pipelined: call q runs on one of two lanes (internal streams, alternating): its edge detection
+    // into the lane's own ext buffer, then its match launch, in stream order.  Nothing orders call q
+    // against call q - 1 on the other lane, so the edges of call q run beside the match of call q - 1,
+    // and the first waves of match q take the SIMD slots that the early finishers of match q - 1 leave
+    // (the younger wave of every SIMD pair ends alone).  Call q - 3 (the one before q - 1
+    // on the other lane) has finished before q starts: at most two calls are in flight.  `stream`
+    // waits for the call's release event: work the caller puts on it afterwards sees the results.
+    SM_TRY(check_plan_pairs(plan, pairs, "sm_run"));
     SM_TRY(use_device(plan->device));
     const int b = plan->cur ^ 1;
-    if (plan->unfenced) {
-        // match launches of a non-pipelined phase left no release events: order the
-        // internal stream behind everything already on `stream`, once
-        SM_HIP(hipEventRecord(plan->ev_free[b], (hipStream_t)stream));
-        plan->ev_free_set[b] = 1;
+    hipStream_t lane = plan->lane[b], user = (hipStream_t)stream;
+    if (plan->unfenced || plan->pipelined == 2) {
+        // work already on `stream` that a lane must not overtake: the launches of a sequential phase
+        // (once, both lanes) or, in ordered mode, whatever produces this call's inputs (this lane)
+        SM_HIP(hipEventRecord(plan->ev_inputs, user));
+        SM_HIP(hipStreamWaitEvent(lane, plan->ev_inputs, 0));
+        if (plan->unfenced) SM_HIP(hipStreamWaitEvent(plan->lane[b ^ 1], plan->ev_inputs, 0));
         plan->unfenced = 0;
     }
-    if (plan->ev_free_set[b]) SM_HIP(hipStreamWaitEvent(plan->edge_stream, plan->ev_free[b], 0));
-    if (plan->pipelined == 2) {
-        // ordered mode: the inputs may have been produced by earlier work on `stream`
-        // (an asynchronous upload, say); the edge kernel waits for it
-        SM_HIP(hipEventRecord(plan->ev_inputs, (hipStream_t)stream));
-        SM_HIP(hipStreamWaitEvent(plan->edge_stream, plan->ev_inputs, 0));
-    }
+    const unsigned q = plan->seq + 1;
+    if (plan->ev_free_set[(q - 3) & 3]) SM_HIP(hipStreamWaitEvent(lane, plan->ev_free[(q - 3) & 3], 0));
+    // what two calls in flight could share: the threshold tables (rebuilt when the threshold
+    // changes), the one int32 staging map of the kernels without a narrow store path, and result
+    // maps the caller hands to consecutive calls -- any of these puts call q behind call q - 1
+    const size_t px = (size_t)pairs * plan->width * plan->height;
+    const uintptr_t lo[2] = {(uintptr_t)d_web, (uintptr_t)d_best};
+    const uintptr_t hi[2] = {lo[0] + px * (web_type == SM_WEB_I32 ? 4 : web_type == SM_WEB_U16 ? 2 : 1),
+                             d_best ? lo[1] + px * 4 : 0};
+    bool shared = !(plan->tab_valid && memcmp(&plan->tab_threshold, &threshold, sizeof threshold) == 0) ||
+                  (web_type != SM_WEB_I32 && plan->kernel != SM_KERNEL_BS);
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            if (lo[i] < plan->out_hi[j] && plan->out_lo[j] < hi[i]) shared = true;
+    if (shared && plan->ev_free_set[(q - 1) & 3]) SM_HIP(hipStreamWaitEvent(lane, plan->ev_free[(q - 1) & 3], 0));
+    plan->seq = q;
     plan->cur = b;
     plan->d_ext = plan->d_ext_buf[b];
-    SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr,
-                         (void *)plan->edge_stream));
-    SM_HIP(hipEventRecord(plan->ev_edges[b], plan->edge_stream));
-    SM_HIP(hipStreamWaitEvent((hipStream_t)stream, plan->ev_edges[b], 0));
-    return sm_match_wta_typed(plan, pairs, d_web, web_type, d_best, stream);
+    for (int i = 0; i < 2; i++) { plan->out_lo[i] = lo[i]; plan->out_hi[i] = hi[i]; }
+    SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, (void *)lane));
+    SM_TRY(sm_match_wta_typed(plan, pairs, d_web, web_type, d_best, (void *)lane));   // records ev_free[q & 3] on the lane
+    SM_HIP(hipStreamWaitEvent(user, plan->ev_free[q & 3], 0));
+    return SM_OK;
 }
 
 extern "C" int sm_debug_planes(sm_plan *plan, int pair, int shift, uint8_t *d_match,

@@ -76,12 +76,13 @@ struct sm_plan {
     size_t ext_bytes;    // of one buffer
     int cur;             // index of d_ext in d_ext_buf
     int pipelined;       // sm_plan_set_pipelined: 0 off, 1 on, 2 on + inputs ordered behind `stream`
-    hipStream_t edge_stream;     // internal: edge detection of call i+1 beside the match of call i
-    hipEvent_t ev_edges[2];      // edges written into buffer b
-    hipEvent_t ev_free[2];       // last match reading buffer b has finished
-    hipEvent_t ev_inputs;        // pipelined == 2: the caller's stream up to this sm_run
-    int ev_free_set[2];
+    hipStream_t lane[2];         // internal: pipelined sm_run i runs (edges, match) on lane i & 1, into buffer i & 1
+    hipEvent_t ev_free[4];       // pipelined call number q has finished: ev_free[q & 3]
+    hipEvent_t ev_inputs;        // the caller's stream up to this sm_run (pipelined == 2, or after a sequential phase)
+    int ev_free_set[4];
+    unsigned seq;                // number of the current / last pipelined sm_run
     int unfenced;                // match launches went out without a release event
+    uintptr_t out_lo[2], out_hi[2];   // [web, best]: what the last pipelined call writes
     // optional timing of the match launches (sm_plan_time_kernels)
     int timing_cap, timing_n, timing_every, timing_seen;
     hipEvent_t *t_begin, *t_end;

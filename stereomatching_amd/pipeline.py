@@ -91,9 +91,10 @@ class StereoPlan:
         return int(lib.sm_plan_workspace_bytes(self._h))
 
     def set_pipelined(self, enabled: bool = True):
-        """Let consecutive run() calls overlap (edges of call i+1 beside the match of
-        call i).  With True the inputs given to run() must be complete in memory at call
-        time; with 2 they may still be in flight on the current stream."""
+        """Let consecutive run() calls overlap (two internal lanes: edges of call i+1 beside
+        the match of call i, the head of match i+1 in the tail of match i; give consecutive
+        calls their own result maps).  With True the inputs given to run() must be complete in
+        memory at call time; with 2 they may still be in flight on the current stream."""
         check(lib.sm_plan_set_pipelined(self._h, int(enabled)))
 
     def prepare_threshold(self, threshold: float = DEFAULT_THRESHOLD):

@@ -557,6 +557,39 @@ def test_pipelined_runs_and_kernel_timing(hip):
         torch.cuda.synchronize()
         assert np.array_equal(host(got)[0], want[i % len(inputs)]), i
     plan.set_pipelined(False)
+    # what two calls in flight could share is put in order by the library: ONE result map for all
+    # calls (the last call's result is what stays), three rotating maps, a threshold that changes
+    # from call to call (the decision tables are rebuilt)
+    plan.set_pipelined(True)
+    torch.cuda.synchronize()
+    one = torch.empty((1, h, w), dtype=torch.int32, device="cuda")
+    for a, b in inputs:
+        plan.run(a, b, 0.15, web=one)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(one)[0], want[-1])
+    three = [torch.empty((1, h, w), dtype=torch.int32, device="cuda") for _ in range(3)]
+    for i in range(3 * len(inputs)):
+        plan.run(*inputs[i % len(inputs)], 0.15, web=three[i % 3])
+    torch.cuda.synchronize()
+    n = 3 * len(inputs)
+    for i in range(n - 3, n):
+        assert np.array_equal(host(three[i % 3])[0], want[i % len(inputs)]), i
+    thr = [0.05, 0.3, 0.15, 0.6]
+    outs = [plan.run(*inputs[0], t)[0] for t in thr]
+    torch.cuda.synchronize()
+    plan.set_pipelined(False)
+    for t, got in zip(thr, outs):
+        assert np.array_equal(host(got)[0], host(plan.run(*inputs[0], t)[0])[0]), t
+    plan.close()
+    # a fallback kernel has ONE int32 staging map for its narrow results: pipelined calls share it
+    plan = hip.StereoPlan(w, h, d, sw, options=dict(kernel_family=1))
+    narrow = [torch.empty((1, h, w), dtype=torch.uint8, device="cuda") for _ in range(len(inputs))]
+    plan.set_pipelined(True)
+    for (a, b), o in zip(inputs, narrow):
+        plan.run(a, b, 0.15, web=o, web_dtype=torch.uint8)
+    torch.cuda.synchronize()
+    for o, exp in zip(narrow, want):
+        assert np.array_equal(host(o)[0].astype(np.int32), exp)
     plan.close()
 
 
