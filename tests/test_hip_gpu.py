@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU
 oracle (tests/oracle.py) and the golden vectors of the compiled reference.
 Everything here is integer / byte work: the bar is bit-exact equality."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -878,6 +880,43 @@ def test_hot_path_random_geometries(hip, w, h, d, sw, mode, dens):
     obest, oweb = oracle.hot_path(le, re, d, sw, mode)
     assert np.array_equal(web[0], oweb), desc
     assert np.array_equal(best[0], obest), desc
+
+
+@pytest.mark.skipif(not os.environ.get("SM_SOAK"), reason="soak run: SM_SOAK=<cases> [SM_SOAK_SEED=<seed>]")
+def test_soak_random_pipelines(hip):
+    """One-off soak (not part of the default suite): SM_SOAK random (size, shifts, window, border,
+    threshold, batch) draws, gray images in, edges + web + best compared with the oracle; sizes reach
+    past 256 columns so that every block shape of the edge kernels (interior / border waves, stacked
+    or side by side) and every kernel family of the plan logic is drawn."""
+    n = int(os.environ["SM_SOAK"])
+    rng = np.random.default_rng(int(os.environ.get("SM_SOAK_SEED", "1")))
+    seen = {}
+    for case in range(n):
+        w = int(rng.choice([rng.integers(1, 64), rng.integers(64, 330), rng.integers(330, 900)]))
+        if rng.integers(0, 3) == 0:
+            w = max(4, w // 4 * 4)
+        h = int(rng.integers(1, 120))
+        sw = int(rng.integers(0, min(26, w, h) + 1))
+        d = int(rng.choice([1, 2, 7, 16, 17, 30, 33, 64, 100, 128, 200, 255, 300]))
+        mode = "ghost" if rng.integers(0, 2) else "toroidal"
+        thr = float(rng.choice([0.0, 0.02, 0.15, 0.15, 0.4, 1.0]))
+        pairs = int(rng.choice([1, 1, 2, 3]))
+        kind = str(rng.choice(["scene", "scene", "noise"]))
+        imgs = [make_pair(w, h, d, seed=int(rng.integers(1 << 30)), kind=kind) for _ in range(pairs)]
+        left = np.stack([p[0] for p in imgs]); right = np.stack([p[1] for p in imgs])
+        plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
+        web, best = plan.run(dev(left), dev(right), thr, want_best=True)
+        el, er = plan.find_all_edges(dev(left), dev(right), thr)
+        what = (case, w, h, d, sw, mode, thr, pairs, kind, plan.describe())
+        for i in range(pairs):
+            o = oracle.pipeline(imgs[i][0], imgs[i][1], thr, d, sw, mode=mode, step3=False)
+            assert np.array_equal(host(el)[i], o["edges-1"]) and np.array_equal(host(er)[i], o["edges-2"]), what
+            assert np.array_equal(host(web)[i], o["web-1"]), what
+            assert np.array_equal(host(best)[i], o["score_best-0"]), what
+        fam = plan.describe().split(":")[0].split("(")[0].strip()
+        seen[fam] = seen.get(fam, 0) + 1
+        plan.close()
+    print(f"soak: {n} cases, all equal to the oracle; kernel families drawn: {seen}")
 
 
 # ---------------------------------------------------------------------------
