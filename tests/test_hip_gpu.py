@@ -783,10 +783,12 @@ def test_cost_kernels_random_shapes_match_own_oracle(hip):
     heights 0 (the plan's) .. 9, images with saturated pixels -- the index arithmetic of the quad-SAD and
     byte-dot kernels (aligned window starts, shift quads, ghost strip, ragged last tiles) against the
     build's own CPU definition."""
-    rng = np.random.default_rng(20261004)
-    for case in range(160):
+    # (SM_SOAK_COST=<cases> [SM_SOAK_SEED=<seed>]: the same sweep, longer and wider, as a one-off soak)
+    soak = int(os.environ.get("SM_SOAK_COST", "0"))
+    rng = np.random.default_rng(int(os.environ.get("SM_SOAK_SEED", "1")) + 977 if soak else 20261004)
+    for case in range(soak or 160):
         sw = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 4, 8]))
-        w = int(rng.integers(max(8, sw), 301))
+        w = int(rng.integers(max(8, sw), 701 if soak else 301))
         if case % 3 == 0:
             w = 4 * ((w + 3) // 4)
         h = int(rng.integers(sw, 60))
@@ -806,6 +808,8 @@ def test_cost_kernels_random_shapes_match_own_oracle(hip):
         assert np.array_equal(host(web)[0], ow), (case, w, h, d, sw, mode, cost, th)
         assert np.array_equal(host(best)[0], ob), (case, w, h, d, sw, mode, cost, th)
         plan.close()
+    if soak:
+        print(f"cost soak: {soak} cases, all equal to the build's own CPU definition")
 
 
 @pytest.mark.parametrize("cfg,cost", [("C3", "sad"), ("C5", "sad"), ("C3", "ssd"), ("C5", "ssd")])
