@@ -19,7 +19,9 @@ w, h, d, sw, mode = CONFIGS[cfg]
 l, r = make_pair(w, h, d, seed=1)
 L = torch.from_numpy(l).cuda().unsqueeze(0).repeat(pairs, 1, 1).contiguous()
 R = torch.from_numpy(r).cuda().unsqueeze(0).repeat(pairs, 1, 1).contiguous()
-plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
+from tools._options import from_env  # noqa: E402
+
+plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs, options=from_env() or None)   # SM_TILE_H=8 ... as the other tools
 plan.find_all_edges(L, R, 0.15, want_edges=False)
 print("#", plan.describe())
 NS = 4
