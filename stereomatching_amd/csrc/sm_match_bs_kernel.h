@@ -570,11 +570,12 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
     // ghost: validity of the window columns (bit i of cv = column x0 - HALF + i)
     u32 cvv[N];
     if (GHOST) {
-        u32 c0 = 0, c1 = 0;
-        for (int i = 0; i < 64; i++) {
-            const int x = x0 - HALF + i;
-            if (x >= 0 && x < g.w) { if (i < 32) c0 |= 1u << i; else c1 |= 1u << (i - 32); }
-        }
+        // bits [lo, hi) of the 64-bit mask {c1, c0}: the columns x0 - HALF + i inside [0, w)
+        const int lo = min(64, max(0, HALF - x0)), hi = min(64, max(0, g.w + HALF - x0));
+        const unsigned long long below_hi = hi >= 64 ? ~0ull : (1ull << hi) - 1ull;
+        const unsigned long long below_lo = lo >= 64 ? ~0ull : (1ull << lo) - 1ull;
+        const unsigned long long cm = hi > lo ? below_hi & ~below_lo : 0ull;
+        const u32 c0 = (u32)cm, c1 = (u32)(cm >> 32);
 #pragma unroll
         for (int i = 0; i < N; i++) cvv[i] = i ? alignbit(c1, c0, i) : c0;
     }
