@@ -69,23 +69,33 @@ __global__ __launch_bounds__(256) void k_cost_wta(const u8 *__restrict__ left,
     u8 *sR = sL + (size_t)g.nsr * g.lrow;
     const int n = g.n, half = g.half;
 
-    // ---- stage rows ty0-half .. with the border rule applied
-    for (int row = 0; row < g.nsr; row++) {
-        const int y = ty0 - half + row;
-        const bool vy = y >= 0 && y < g.h;
-        const int ys = GHOST ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
+    // ---- stage rows ty0-half .. with the border rule applied.  Eight rows at a time: the eight byte
+    // loads of a lane are all issued before the first is stored (one row per trip paid one memory round
+    // trip per row and column block: 72 trips in the ghost strip's 64-thread workgroups, 60 of their 70 us)
+    constexpr int SR = 8;
+    for (int row0 = 0; row0 < g.nsr; row0 += SR) {
         for (int b = tid; b < g.lrow + g.rrow; b += (int)blockDim.x) {
             const bool is_r = b >= g.lrow;
             const int bb = is_r ? b - g.lrow : b;
             const int x = tx0 - g.pad + bb;
-            u8 v = 0;
-            if (GHOST) {
-                if (vy && x >= 0 && x < g.w) v = (is_r ? R : L)[(size_t)ys * g.w + x];
-            } else {
-                const int xs = ((x % g.w) + g.w) % g.w;
-                v = (is_r ? R : L)[(size_t)ys * g.w + xs];
+            // (every load is unconditional, from an address clamped into the image: a load under a
+            // condition is waited for at the end of its branch)
+            const int xs = GHOST ? min(max(x, 0), g.w - 1) : ((x % g.w) + g.w) % g.w;
+            const bool vx = !GHOST || (x >= 0 && x < g.w);
+            const u8 *src = is_r ? R : L;
+            u8 v[SR];
+#pragma unroll
+            for (int u = 0; u < SR; u++) {
+                const int y = ty0 - half + row0 + u;
+                const bool vy = y >= 0 && y < g.h;
+                const int ys = GHOST ? min(max(y, 0), g.h - 1) : ((y % g.h) + g.h) % g.h;
+                const u8 raw = src[(size_t)ys * g.w + xs];
+                v[u] = (vx && (vy || !GHOST)) ? raw : (u8)0;
             }
-            (is_r ? sR + (size_t)row * g.rrow : sL + (size_t)row * g.lrow)[bb] = v;
+#pragma unroll
+            for (int u = 0; u < SR; u++)
+                if (row0 + u < g.nsr)
+                    (is_r ? sR + (size_t)(row0 + u) * g.rrow : sL + (size_t)(row0 + u) * g.lrow)[bb] = v[u];
         }
     }
     __syncthreads();

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""profiles/cost_valu.json (what bench.py's `sad` / `ssd` objects price their launches with) from the
+summaries tools/cost_pmc.sh left under profiles/<round>/cost_<cost>_<cfg>.json.
+    python tools/make_cost_valu.py profiles/r03"""
+import json
+import re
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from stereomatching_amd.synth import CONFIGS  # noqa: E402
+
+src = Path(sys.argv[1])
+out = {}
+for f in sorted(src.glob("cost_*_C*.json")):
+    cost, cfg = re.match(r"cost_(sad|ssd)_(C\d)\.json", f.name).groups()
+    d = json.loads(f.read_text())
+    w, h, shifts, _, _ = CONFIGS[cfg]
+    valu = sum(v for k, v in d["counters_per_launch"].items() if k.endswith("|SQ_INSTS_VALU"))
+    names = [re.sub(r"^void ", "", k["Name"]).split("(")[0] for k in d["kernel_stats"]]
+    out[f"{cfg}:{cost}"] = {
+        "kernel": names[0] + (f" + ghost strip {names[1].split('<')[0]}" if len(names) > 1 else ""),
+        "valu_wave_instructions": int(round(valu)),
+        "kernel_trace_avg_ns": {n: round(float(k["AverageNs"]), 2) for n, k in zip(names, d["kernel_stats"])},
+        "lane_instructions_per_pixel_shift": round(valu * 64 / (float(w) * h * shifts), 2),
+        "source": f"{f.relative_to(ROOT) if f.is_absolute() else f} (rocprofv3 --pmc SQ_INSTS_VALU, separate passes)",
+    }
+order = ["C3:sad", "C5:sad", "C3:ssd", "C5:ssd"]
+out = {k: out[k] for k in order if k in out} | {k: v for k, v in out.items() if k not in order}
+(ROOT / "profiles" / "cost_valu.json").write_text(json.dumps(out, indent=1) + "\n")
+print(json.dumps(out, indent=1))
