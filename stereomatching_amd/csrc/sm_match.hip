@@ -505,6 +505,7 @@ int sm_match_configure(sm_plan *plan)
         g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = g.ds = 0;
         g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = g.cap2 = g.duo = 0;
         g.prio_pattern = 0;
+        g.prio_shift = 0;
         g.edge_words_l = g.edge_words_r = g.ext_words;
         snprintf(plan->describe, sizeof plan->describe,
                  "generic kernel (n=%d, D=%d): 1 lane/pixel, direct window sums", g.n, D);
@@ -701,15 +702,21 @@ int sm_match_configure(sm_plan *plan)
     }
     g.prio_pattern = sm_bs_default_pattern(g.duo != 0);
     if (plan->opt.priority_pattern) g.prio_pattern = plan->opt.priority_pattern;   // tuning
+    // the bit that tells a SIMD's two waves apart (see the kernel): the workgroup's slot on its CU where
+    // two-wave workgroups fill the chip in ONE round (2 waves on each of the 4 SIMDs of a CU), else the wave slot
+    g.prio_shift = 0;
+    if (bs && g.duo && (long long)g.tiles_x * g.tiles_y * plan->max_pairs <= 4LL * cus) g.prio_shift = 16;
+    if (plan->opt.priority_class) g.prio_shift = plan->opt.priority_class == 2 ? 16 : 0;   // tuning
 
     snprintf(plan->describe, sizeof plan->describe,
              "%s (n=%d, D=%d, %s): tile %dx%d px, %d threads "
-             "(%d runs x %d shift-lanes of %d), grid %dx%d, LDS %d B/wg%s, ext %dx%d words",
+             "(%d runs x %d shift-lanes of %d), grid %dx%d, LDS %d B/wg%s%s, ext %dx%d words",
              bs ? "bit-sliced kernel" : kernel == SM_KERNEL_A ? "tiled kernel A"
                 : kernel == SM_KERNEL_B ? "tiled kernel B" : "tiled kernel C",
              g.n, D, ghost ? "ghost" : "toroidal",
              g.tw, g.duo ? 2 * g.tile_h : g.tile_h, g.threads, g.runs, g.nl, g.ds, g.tiles_x, g.tiles_y, g.lds_bytes,
-             g.duo ? ", two-wave workgroups" : g.cap2 ? ", 2 waves/SIMD variant" : "", g.ext_words, g.ext_rows);
+             g.duo ? ", two-wave workgroups" : g.cap2 ? ", 2 waves/SIMD variant" : "",
+             g.prio_shift ? " favoured by workgroup slot" : "", g.ext_words, g.ext_rows);
     return SM_OK;
 }
 

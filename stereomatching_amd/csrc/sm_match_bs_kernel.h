@@ -502,7 +502,15 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
     // and gives the other what is left (measured: 4.9 vs 9.0 cycles per instruction here);
     // without the swap the favoured wave finishes a third earlier and the SIMD then runs
     // half empty until the other is done.
-    const unsigned slot_parity = __builtin_amdgcn_s_getreg(63492) & 1;
+    // Which of a SIMD's two waves a slice favours: bit g.prio_shift of HW_ID -- bit 0 of the wave slot, or
+    // (two-wave workgroups of a launch that fits the chip in one round) bit 0 of TG_ID, the workgroup's slot
+    // on its CU.  The two waves of a SIMD differ in either (tools/wave_timeline.py: 1016 of 1016 pairs), but
+    // the two waves of a WORKGROUP share the second: their barrier-coupled warm-up is then favoured as a
+    // whole instead of running at the pace of whichever of the two is not (a workgroup with one wave in
+    // each slot parity -- half of them -- was never favoured as a whole).  In a launch of several rounds
+    // later workgroups land in whatever slot is free and the bit no longer separates a SIMD's pair:
+    // those keep the wave slot.
+    const unsigned slot_parity = (__builtin_amdgcn_s_getreg(63492) >> g.prio_shift) & 1;
     // the clock is read one row ahead of its use (s_memtime is a scalar memory read: its
     // value takes ~100 cycles to arrive, and a wave that uses it at once waits that long)
     unsigned long long clk = __builtin_amdgcn_s_memtime();

@@ -17,6 +17,7 @@ NAMES = {
     "SM_COST_PX": lambda v: {"cost_pixels_per_lane": int(v)},
     "SM_COST_TILE_H": lambda v: {"cost_tile_h": int(v)},
     "SM_COST_KERNEL": lambda v: {"cost_kernel": int(v)},
+    "SM_PRIO_CLASS": lambda v: {"priority_class": int(v)},
 }
 
 
@@ -35,7 +36,8 @@ class PlanOptions(C.Structure):     # sm_plan_options, for tools that load a lib
     _fields_ = [("struct_size", C.c_int), ("kernel_family", C.c_int), ("tile_h", C.c_int),
                 ("shifts_per_lane", C.c_int), ("workgroup_waves", C.c_int), ("no_two_wave_cap", C.c_int),
                 ("priority_pattern", C.c_uint), ("edge_kernel", C.c_int), ("timing_by_records", C.c_int),
-                ("cost_pixels_per_lane", C.c_int), ("cost_tile_h", C.c_int), ("cost_kernel", C.c_int)]
+                ("cost_pixels_per_lane", C.c_int), ("cost_tile_h", C.c_int), ("cost_kernel", C.c_int),
+                ("priority_class", C.c_int)]
 
 
 def struct_from_spec(spec: dict) -> PlanOptions:

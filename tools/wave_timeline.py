@@ -125,6 +125,25 @@ for rep in range(3):
             m = s0 == sl
             print(f"    workgroups whose wave 0 is in slot {int(sl)}: {int(m.sum())}, linear index pct "
                   f"{np.percentile(wg_lin[m], [0, 10, 50, 90, 100]).round(0)}")
+    # threadgroup slot of the wave's workgroup on its CU (HW_ID.TG_ID): do the two waves that share a
+    # SIMD always come from workgroups of different halves (slots 0, 1 against 2, 3)?
+    tg = (hwid >> 16) & 0xf
+    print("  threadgroup ids in use:", dict(zip(*np.unique(tg, return_counts=True))))
+    if len(pair):
+        tgo = tg[order]
+        ta, tb = tgo[pair], tgo[pair + 1]
+        print("  SIMD pairs by (tg, tg):", {(int(a_), int(b_)): int(((np.minimum(ta, tb) == a_) & (np.maximum(ta, tb) == b_)).sum())
+                                            for a_ in np.unique(tg) for b_ in np.unique(tg)
+                                            if ((np.minimum(ta, tb) == a_) & (np.maximum(ta, tb) == b_)).any()})
+        print(f"  SIMD pairs whose waves differ in tg bit 1: {int((((ta ^ tb) >> 1) & 1).sum())} of {len(pair)}; "
+              f"in tg bit 0: {int(((ta ^ tb) & 1).sum())}; in slot bit 0: "
+              f"{int(((slot[order][pair] ^ slot[order][pair + 1]) & 1).sum())}")
+    if wpw == 2:
+        print("  workgroups whose two waves report the same tg:", int((tg[0::2] == tg[1::2]).sum()), "of", len(tg) // 2)
+        for t_ in np.unique(tg):
+            m = tg == t_
+            print(f"    tg {int(t_)}: waves {int(m.sum())}, warm-up median {np.median((rt[:, 2] - rt[:, 1])[m]):.2f} us, "
+                  f"lifetime median {np.median(life[m]):.1f} us, slots {dict(zip(*np.unique(slot[m], return_counts=True)))}")
     single = np.flatnonzero(np.isin(simd_key, uniq[cnt == 1]))
     if len(single):
         print(f"  waves alone on their SIMD: {len(single)}, lifetime median {np.median(life[single]):.1f} us")
