@@ -144,6 +144,14 @@ for rep in range(3):
             m = tg == t_
             print(f"    tg {int(t_)}: waves {int(m.sum())}, warm-up median {np.median((rt[:, 2] - rt[:, 1])[m]):.2f} us, "
                   f"lifetime median {np.median(life[m]):.1f} us, slots {dict(zip(*np.unique(slot[m], return_counts=True)))}")
+    if wpw == 2:
+        # by dispatch order: workgroups in blocks of one per CU
+        lin = np.arange(len(tg)) // 2
+        ncu = len(np.unique(key))
+        for b in range((lin.max() + ncu) // ncu):
+            m = (lin // ncu == b) & ok
+            print(f"    workgroups {b * ncu}..{(b + 1) * ncu - 1}: tg {dict(zip(*np.unique(tg[m], return_counts=True)))}, "
+                  f"lifetime median {np.median(life[m]):.1f} us (10 % {np.percentile(life[m], 10):.1f}, 90 % {np.percentile(life[m], 90):.1f})")
     single = np.flatnonzero(np.isin(simd_key, uniq[cnt == 1]))
     if len(single):
         print(f"  waves alone on their SIMD: {len(single)}, lifetime median {np.median(life[single]):.1f} us")
