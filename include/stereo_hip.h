@@ -120,6 +120,8 @@ typedef struct sm_plan_options {
     int priority_class;         /* bit-sliced kernel: which of a SIMD's two waves a priority slice favours is told by
                                  * 1 = the wave slot's parity, 2 = the parity of the workgroup's slot on its CU (the two
                                  * waves of a two-wave workgroup are then favoured together); 0 = the plan's choice */
+    int priority_on_change;     /* bit-sliced kernel: 1 = s_setprio only when the wanted priority changes, 2 = once per row;
+                                 * 0 = the plan's choice */
 } sm_plan_options;
 int sm_plan_create_ex(int device, int width, int height, int num_shifts, int square_width,
                       int border, int max_pairs, const sm_plan_options *options, sm_plan **out);

@@ -60,6 +60,7 @@ struct MatchGeom {
     int duo;             // bit-sliced kernel: two-wave workgroups of 2 * tile_h rows (shared warm-up)
     unsigned prio_pattern;   // bit-sliced kernel: the time-sliced priority schedule (sm_match_bs_kernel.h)
     int prio_shift;          // ... the HW_ID bit that tells a SIMD's two waves apart: 0 wave slot, 16 workgroup slot (TG_ID)
+    int prio_on_change;      // ... s_setprio only when the wanted priority changes (else once per row)
     int web_bytes;       // bytes per element of the web map of THIS launch: 4 (int32), 2, 1
     // ext words per row that can reach a valid output pixel (left image: columns up to W - 1 + half;
     // right: + D - 1 more); the edge kernels compute no others (the tile round-up stays zero)

@@ -506,6 +506,7 @@ int sm_match_configure(sm_plan *plan)
         g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = g.cap2 = g.duo = 0;
         g.prio_pattern = 0;
         g.prio_shift = 0;
+        g.prio_on_change = 0;
         g.edge_words_l = g.edge_words_r = g.ext_words;
         snprintf(plan->describe, sizeof plan->describe,
                  "generic kernel (n=%d, D=%d): 1 lane/pixel, direct window sums", g.n, D);
@@ -707,6 +708,7 @@ int sm_match_configure(sm_plan *plan)
     g.prio_shift = 0;
     if (bs && g.duo && (long long)g.tiles_x * g.tiles_y * plan->max_pairs <= 4LL * cus) g.prio_shift = 16;
     if (plan->opt.priority_class) g.prio_shift = plan->opt.priority_class == 2 ? 16 : 0;   // tuning
+    g.prio_on_change = plan->opt.priority_on_change == 1;                                 // tuning (default: once per row)
 
     snprintf(plan->describe, sizeof plan->describe,
              "%s (n=%d, D=%d, %s): tile %dx%d px, %d threads "
