@@ -79,6 +79,15 @@ def test_plan_options_struct_and_argument_checks():
     csrc = ROOT / "stereomatching_amd" / "csrc"
     for f in list(csrc.glob("*.hip")) + list(csrc.glob("*.h")):
         assert "getenv" not in f.read_text(), f
+    # the tuning tools load libraries by hand and carry their own mirror of the struct: same fields, and
+    # every short name they accept maps onto one of them
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from tools import _options
+    assert [n for n, _ in _options.PlanOptions._fields_] == fields
+    for name, to_fields in _options.NAMES.items():
+        probe = "popcount" if name == "SM_KERNEL" else ("0x3" if name == "SM_PATTERN" else "2")
+        assert set(to_fields(probe)) <= set(fields), name
 
 
 def test_product_package_never_touches_the_oracle():
