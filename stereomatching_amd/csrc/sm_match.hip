@@ -703,10 +703,11 @@ int sm_match_configure(sm_plan *plan)
     }
     g.prio_pattern = sm_bs_default_pattern(g.duo != 0);
     if (plan->opt.priority_pattern) g.prio_pattern = plan->opt.priority_pattern;   // tuning
-    // the bit that tells a SIMD's two waves apart (see the kernel): the workgroup's slot on its CU where
-    // two-wave workgroups fill the chip in ONE round (2 waves on each of the 4 SIMDs of a CU), else the wave slot
+    // the bit that tells a SIMD's two waves apart (see the kernel): the wave slot.  The workgroup's slot on its
+    // CU (priority_class 2) wins 1-2 % (6 % at 21 x 21) when the match launch follows ITSELF, as in a timing loop
+    // of match launches -- and LOSES 5 % in the real step, where it follows the edge kernel and its workgroups
+    // find other slots (tools/sustained_ab.sh, profiles/r03/sustained_ab.txt): an option for tuning, not the default
     g.prio_shift = 0;
-    if (bs && g.duo && (long long)g.tiles_x * g.tiles_y * plan->max_pairs <= 4LL * cus) g.prio_shift = 16;
     if (plan->opt.priority_class) g.prio_shift = plan->opt.priority_class == 2 ? 16 : 0;   // tuning
     g.prio_on_change = plan->opt.priority_on_change == 1;                                 // tuning (default: once per row)
 
