@@ -17,10 +17,12 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
 w, h, d, sw, mode = CONFIGS[cfg]
+pairs = int(os.environ.get("PAIRS", "1"))            # pairs per step (C4: PAIRS=8)
 l, r = make_pair(w, h, d, seed=1)
-L, R = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
-plan = pipeline.StereoPlan(w, h, d, sw, mode, options=from_env() or None)
-web = torch.empty((1, h, w), dtype=torch.int32, device="cuda")
+L = torch.from_numpy(l).cuda().unsqueeze(0).repeat(pairs, 1, 1).contiguous()
+R = torch.from_numpy(r).cuda().unsqueeze(0).repeat(pairs, 1, 1).contiguous()
+plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=pairs, options=from_env() or None)
+web = torch.empty((pairs, h, w), dtype=torch.int32, device="cuda")
 print("#", plan.describe(), flush=True)
 t_start = time.perf_counter()
 for c in range(chunks):
