@@ -5,6 +5,12 @@ timed in interleaved rounds (timings from different gpurun boxes differ by up
 to ~10 %, so variants must never be compared across calls).
 
     python tools/ab_variants.py [C3] [pairs] [rounds]
+
+The default loop times the match launch after ITSELF.  That ranks kernel builds correctly
+(instruction counts, staging, tiling) but NOT wave-priority schedules: the match launch that
+follows the edge kernel finds its workgroups in other slots (round 3: a priority class that won
+1-2 % here lost 5 % in the real step).  For those use AB_STEP=1 (edges, then match, per
+iteration) or tools/sustained_ab.sh.
 """
 import ctypes as C
 import statistics
