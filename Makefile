@@ -40,7 +40,7 @@ CPU_PROGRAMS := $(O)/stereomatch $(O)/stereomatch-ghost
 GPU_PROGRAMS := $(O)/stereopar $(O)/stereopar-ghost
 BATCH_PROGRAM := $(O)/stereopar-batch
 
-all: $(CPU_PROGRAMS) $(GPU_PROGRAMS) $(BATCH_PROGRAM)
+all: $(CPU_PROGRAMS) $(GPU_PROGRAMS) $(BATCH_PROGRAM) $(BATCH_PROGRAM)-testhooks
 
 $(O):
 	mkdir -p $@
@@ -74,6 +74,9 @@ $(GPU_PROGRAMS): $(HOSTDIR)/stereopar.c $(O)/image.o $(O)/image_gpu.o $(DEVLIB)
 # a batch of pairs over all visible GPUs (not in the reference: its programs do one pair)
 $(BATCH_PROGRAM): $(HOSTDIR)/stereopar_batch.c $(HOSTDIR)/batch_index.h $(O)/image.o $(DEVLIB)
 	$(CC) $(CFLAGS) $(filter %.c %.o,$^) -o $@ $(LINKDEV) -lm -lpthread
+# the same program with its failure-injection option (-x): for the tests only, not the product
+$(BATCH_PROGRAM)-testhooks: $(HOSTDIR)/stereopar_batch.c $(HOSTDIR)/batch_index.h $(O)/image.o $(DEVLIB)
+	$(CC) $(CFLAGS) -DSTEREOPAR_BATCH_TEST_HOOKS $(filter %.c %.o,$^) -o $@ $(LINKDEV) -lm -lpthread
 
 clean:
 	rm -rf debug timing release *.ppm

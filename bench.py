@@ -31,6 +31,10 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 throughput bar, NOT traffic: the fused kernel never moves it).
   cpu_baseline  the oracle's structure-faithful C port timed on this host's
                 cores on a bounded band of the same workload (rank 0, N = 1)
+  c4            (N > 1, or --c4) SURVEY.md 8e's scaling workload beside the C3 weak-scaling `value`: the batch of
+                64 x 1080p pairs (64 shifts, 7x7), pair j -> rank j mod N, each rank's share in ONE launch per
+                step, timed under the same barrier / max-over-ranks contract (strong scaling: 64 pairs whatever
+                N), plus `gather_ms`: the collection of the 64 maps on rank 0 (RCCL point to point), timed apart
   sad, ssd      (N = 1) the SAD / SSD cost mode -- the cost BASELINE.json's wording names, which
                 the reference does not implement: PARITY UNPINNED, the build's own definition --
                 at C3 (SAD 9x9) and C5 (SSD 11x11, ghost): ms per launch, Mpixel-disparities/s and
@@ -85,6 +89,9 @@ def parse(argv=None):
                          "measured +1.4 %% at C3, profiles/r03/ab_pipelined_lanes.txt).  Off by default: a step is "
                          "then no longer one serial pass, and the per-launch kernel time is that of launches "
                          "sharing the chip")
+    ap.add_argument("--c4", action="store_true",
+                    help="add the `c4` object (64 x 1080p pairs sharded over the ranks + the collection of the maps "
+                         "on rank 0) also at N = 1; at N > 1 it is always there")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region, collect the maps on rank 0 over RCCL and time it")
     ap.add_argument("--no-e2e", action="store_true",
@@ -253,6 +260,115 @@ def cost_modes(dev):
     return res
 
 
+C4_TOTAL_PAIRS = 64
+C4_DISTINCT = 4                 # different synthetic pairs per rank (the rest of its share repeats them)
+
+
+def c4_leg(rank, world, dev, red_dev, steps, threshold, rehearsal, dryrun):
+    """The extra `c4` object: BASELINE config 4 / SURVEY.md 8e -- 64 x 1080p pairs, 64 shifts, 7x7, pair j ->
+    rank j mod world, every rank's share in ONE launch per step, no data-path collective; then the maps are
+    collected on rank 0 (shard.gather_maps: RCCL point to point) and that is timed apart.  Strong scaling: the
+    job is 64 pairs whatever the world size.  Returns the object on rank 0, None elsewhere."""
+    import torch
+    from stereomatching_amd import shard
+    from stereomatching_amd.synth import CONFIGS
+
+    w, h, d, sw, mode = CONFIGS["C4"]
+    mine = shard.pairs_for_rank(C4_TOTAL_PAIRS, rank, world)
+    share = len(mine)
+    steps = max(1, min(steps, 50))
+    obj = {"workload": f"C4: {C4_TOTAL_PAIRS} x ({w}x{h} pair, {d} shifts, {sw}x{sw} window, {mode} border), pair j -> "
+                       f"rank j mod {world}; each rank's share ({share} pairs on rank 0) in ONE launch per step",
+           "total_pairs": C4_TOTAL_PAIRS, "pairs_per_rank": share, "steps": steps, "scaling": "strong",
+           "unit": "Mpixel-disparities/s"}
+    if dryrun:
+        # plumbing only: the sharding, the barriers and the collection, on tiny stand-in maps whose value is
+        # the index of the pair they belong to
+        local = torch.stack([torch.full((4, 8), j, dtype=torch.int32) for j in mine]) if mine else \
+            torch.zeros((0, 4, 8), dtype=torch.int32)
+        shard.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            time.sleep(0.0005)
+        shard.barrier()
+        elapsed = shard.max_over_ranks(time.perf_counter() - t0, "cpu")
+        g0 = time.perf_counter()
+        got = shard.gather_maps(local, C4_TOTAL_PAIRS, rank, world)
+        gather = shard.max_over_ranks(time.perf_counter() - g0, "cpu")
+        if rank != 0:
+            return None
+        ok = all(bool((got[j] == j).all()) for j in range(C4_TOTAL_PAIRS))
+        obj.update(dry_run=True, value=0.0, ms_per_step=round(elapsed / steps * 1e3, 4),
+                   gather_ms=round(gather * 1e3, 3), maps_in_pair_order=ok)
+        return obj
+
+    import numpy as np
+    from stereomatching_amd import pipeline
+    from stereomatching_amd.synth import make_pair
+    plan = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=max(1, share), device=dev.index)
+    # pair j carries the synthetic pair number (j // world) % C4_DISTINCT: the same content on every rank
+    # at the same position of its share, so that rank 0 can check the collected maps against its own
+    base = [make_pair(w, h, d, seed=4000 + k) for k in range(min(C4_DISTINCT, max(1, share)))]
+    idx = [(j // world) % C4_DISTINCT for j in mine] or [0]
+    left = torch.from_numpy(np.stack([base[k][0] for k in idx])).to(dev)
+    right = torch.from_numpy(np.stack([base[k][1] for k in idx])).to(dev)
+    web = torch.empty((len(idx), h, w), dtype=torch.int32, device=dev)
+    plan.prepare_threshold(threshold)
+    n = len(idx) if share else 0
+
+    def step():
+        if n:
+            plan.run(left, right, threshold, web=web)
+    t_end = time.perf_counter() + WARMUP_FLOOR_S
+    k = 0
+    while k < 3 or time.perf_counter() < t_end:
+        step()
+        k += 1
+    torch.cuda.synchronize(dev)
+    shard.barrier()
+    for _ in range(4):
+        step()
+    shard.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    shard.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, red_dev)
+    # collection of the maps on rank 0, timed apart (never part of a step)
+    local = web[:share]
+    torch.cuda.synchronize(dev)
+    shard.barrier()
+    g0 = time.perf_counter()
+    got = shard.gather_maps(local.cpu() if rehearsal else local, C4_TOTAL_PAIRS, rank, world)
+    torch.cuda.synchronize(dev)
+    gather = shard.max_over_ranks(time.perf_counter() - g0, red_dev)
+    plan.close()
+    if rank != 0:
+        return None
+    mine0 = local.cpu() if rehearsal else local
+    ok = got.shape[0] == C4_TOTAL_PAIRS and all(
+        bool(torch.equal(got[j], mine0[(j // world) % min(C4_DISTINCT, share)])) for j in range(C4_TOTAL_PAIRS))
+    inbound = (C4_TOTAL_PAIRS - share) * w * h * 4
+    obj.update(value=round(float(w) * h * d * C4_TOTAL_PAIRS * steps / elapsed / 1e6, 1),
+               ms_per_step=round(elapsed / steps * 1e3, 4), kernel=plan_desc_short(w, h, d, sw, mode, share, dev),
+               gather_ms=round(gather * 1e3, 3), gather_bytes_inbound=inbound,
+               gather_GBps=round(inbound / gather / 1e9, 1) if gather > 0 and inbound else None,
+               gather_transport="gloo over host memory (rehearsal)" if rehearsal else
+                                "RCCL point to point (ncclSend / ncclRecv under torch.distributed), maps device to device",
+               maps_in_pair_order=bool(ok))
+    return obj
+
+
+def plan_desc_short(w, h, d, sw, mode, share, dev):
+    from stereomatching_amd import pipeline
+    p = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=max(1, share), device=dev.index)
+    text = p.describe()
+    p.close()
+    return text
+
+
 def timing_stride(steps: int) -> int:
     """Bracket every `stride`-th match launch with HIP events: an event record costs
     ~4 us on the launch stream (tools/gap_probe.py), so long runs sample every 8th
@@ -337,13 +453,17 @@ def main():
             time.sleep(0.0005)
         shard.barrier()
         elapsed = shard.max_over_ranks(time.perf_counter() - t0, "cpu")
+        c4 = c4_leg(rank, world, None, "cpu", args.steps, args.threshold, True, True) if (world > 1 or args.c4) else None
         if rank == 0:
-            emit(json.dumps({"metric": "Mpixel-disparities/s", "value": 0.0,
-                             "unit": "Mpixel-disparities/s", "n_gpus": world, "steps": args.steps,
-                             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                             "dry_run": True, "data": "none: SM_BENCH_DRYRUN plumbing rehearsal, no GPU work",
-                             "config": {"workload": f"{args.config} x {pairs} pair(s)/rank (not run)"}}))
+            line = {"metric": "Mpixel-disparities/s", "value": 0.0,
+                    "unit": "Mpixel-disparities/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dry_run": True, "data": "none: SM_BENCH_DRYRUN plumbing rehearsal, no GPU work",
+                    "config": {"workload": f"{args.config} x {pairs} pair(s)/rank (not run)"}}
+            if c4 is not None:
+                line["c4"] = c4
+            emit(json.dumps(line))
         shard.finalize()
         return
 
@@ -446,20 +566,28 @@ def main():
         torch.cuda.synchronize(dev)
         gather_ms = shard.max_over_ranks(time.perf_counter() - g0, red_dev) * 1e3
 
+    # SURVEY 8e's scaling workload beside the weak-scaling headline (every rank takes part)
+    c4 = None
+    plan_geo_keep = (plan.geometry(), plan.describe(), plan.valu_model(pairs, want_best=args.with_best))
+    if world > 1 or args.c4:
+        plan.close()
+        del left, right, web, best
+        torch.cuda.empty_cache()
+        c4 = c4_leg(rank, world, dev, red_dev, args.steps, args.threshold, rehearsal, False)
+
     if rank != 0:
         shard.finalize()
         return
 
     kernel_s = kernel_ms * 1e-3
     acv = A_CV_BYTES * units_per_step / kernel_s / 1e9             # GB/s (throughput bar)
-    geo = plan.geometry()
+    geo, plan_text, model = plan_geo_keep
     compulsory = 4.0 * w * h * pairs + 2 * 4.0 * geo["ext_words"] * geo["ext_rows"] * pairs     # web out + packed edge bits in
     amin_kernel = compulsory / kernel_s / 1e9
     amin_step = A_MIN_BYTES * w * h * pairs / (elapsed / args.steps) / 1e9
     # VALU wave-instructions of one launch: the plan's analytic model (per-wave set-up +
     # warm-up rows + output rows, coefficients fitted to SQ_INSTS_VALU of rocprofv3 --pmc
     # passes at several tile heights: stereomatching_amd/valu_counts.json)
-    model = plan.valu_model(pairs, want_best=args.with_best)
     # HBM bytes of one launch: separate rocprofv3 --pmc passes of this same command
     # (tools/collect_profiles.sh), committed under profiles/; null if none for this config
     traffic = traffic_src = None
@@ -472,7 +600,7 @@ def main():
 
     roof = {
         "bound": "valu",
-        "kernel": "k_match_bs" if "bit-sliced" in plan.describe() else "k_match_wta",
+        "kernel": "k_match_bs" if "bit-sliced" in plan_text else "k_match_wta",
         "achieved": None, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s", "frac": None,
         "peak_definition": "1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction "
                            "(MI355X_MICROARCH.md)",
@@ -482,7 +610,7 @@ def main():
         "kernel_launches_timed": n_timed,
         "kernel_ms_method": ("start / end time stamps of the dispatch itself (hipExtLaunchKernel events: the "
                              "clock rocprofv3's kernel trace reads), on the launch stream"
-                             if "bit-sliced" in plan.describe() else
+                             if "bit-sliced" in plan_text else
                              "HIP event records around the launch, on the launch stream"),
     }
     if model:
@@ -530,7 +658,7 @@ def main():
         "config": {
             "workload": f"{args.config}: {w}x{h} pair, {d} shifts, {sw}x{sw} window, {mode} border, "
                         f"{pairs} pair(s)/GPU/step; edges + fused match/aggregate/WTA -> web",
-            "kernel": plan.describe(),
+            "kernel": plan_text,
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
             "pipelined": args.pipeline,
         },
@@ -542,9 +670,12 @@ def main():
         out["gather_ms"] = round(gather_ms, 3)
     if e2e is not None:
         out["e2e"] = e2e
+    if c4 is not None:
+        out["c4"] = c4
     if world == 1 and not args.no_cost_modes and not rehearsal:
-        plan.close()
-        del left, right, web
+        if c4 is None:
+            plan.close()
+            del left, right, web
         out.update(cost_modes(dev))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, d, sw, mode, args.cpu_rows, args.threshold)

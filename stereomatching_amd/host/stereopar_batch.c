@@ -29,8 +29,9 @@
  *     -o DIR        write each web map to DIR/web-<index>.pgm (binary PGM, maxval =
  *                   shifts; DIR must exist).  Default: no files (timing).
  *     -r REPEAT     process the list REPEAT times (throughput measurements)
- *     -x N          test hook: every device reports a failure when it is about to submit its
- *                   N-th batch (exercises the error path of the two host threads per device)
+ *   builds with -DSTEREOPAR_BATCH_TEST_HOOKS (the test and ThreadSanitizer builds, never the product) add
+ *     -x N          every device reports a failure when it is about to submit its N-th batch
+ *                   (exercises the error path of the two host threads per device)
  *
  * stdout: one line
  *   pairs = P, devices = K, width = W, height = H, shifts = D, elapsed = T, pairs_per_s = R, checksum = C
@@ -93,7 +94,9 @@ typedef struct {
      * slot_free): the semaphores order them.  The end is signalled separately -- `submitted` =
      * batches handed over so far, `finished` = no more will come -- never by rewriting the fields
      * of a set the collector may be looking at. */
-    int in_flight[SLOTS], first_index[SLOTS];     /* pairs in the set, first pair's index */
+    int in_flight[SLOTS];                         /* pairs in the set */
+    long first_index[SLOTS];                      /* the first pair's index in this device's sequence (mine * repeat
+                                                   * can pass 2^31) */
     atomic_long submitted;
     atomic_int finished;
     void *ev_down[SLOTS], *h_web[SLOTS];
@@ -215,8 +218,14 @@ static void *collector_main(void *arg)
     for (int s = 0;; s = (s + 1) % SLOTS, processed++) {
         sem_wait(&w->slot_filled);
         /* one post per submitted batch, and one more when the submitter is done or has failed */
-        if (atomic_load(&w->failed) || processed == atomic_load(&w->submitted))
+        if (atomic_load(&w->failed))
             break;
+        if (processed == atomic_load(&w->submitted)) {
+            /* a post with no batch behind it: the end signal (`finished` is set before that post) */
+            if (!atomic_load(&w->finished))
+                set_failed(w, "error: collector woken without a batch or the end signal");
+            break;
+        }
         const int b = w->in_flight[s];
         if (sm_event_sync(w->device, w->ev_down[s]) != SM_OK)
             set_failed(w, sm_last_error());
@@ -306,10 +315,12 @@ static void *worker_main(void *arg)
     long next = 0, batches = 0;           /* index into this device's sequence of pairs; batches submitted */
     for (int s = 0; next < total && !atomic_load(&w->failed); s = (s + 1) % SLOTS) {
         sem_wait(&w->slot_free);          /* the collector is done with this set's previous maps */
+#ifdef STEREOPAR_BATCH_TEST_HOOKS
         if (w->fail_at && batches + 1 == w->fail_at) {
             set_failed(w, "error: injected failure (-x)");
             goto out;
         }
+#endif
         /* upload the next batch straight from the pinned arena the images were decoded
          * into: lefts then rights, as sm_run expects a batch (no staging copy on the host).
          * The set's input buffer is free once the kernels that last read it have run,
@@ -332,7 +343,7 @@ static void *worker_main(void *arg)
         W_TRY(sm_memcpy_d2h_async(dev, w->h_web[s], d_web[s], n * web_bytes * b, st_down));
         W_TRY(sm_event_record(dev, w->ev_down[s], st_down));
         used[s] = 1;
-        w->first_index[s] = (int)next;
+        w->first_index[s] = next;
         w->in_flight[s] = b;
         next += b;
         atomic_store(&w->submitted, ++batches);
@@ -394,7 +405,12 @@ int main(int argc, char *argv[])
     for (; a < argc && argv[a][0] == '-' && argv[a][1]; a++) {
         const char opt = argv[a][1];
         if (opt == 'g') { border = SM_GHOST; continue; }
-        if (a + 1 >= argc || !strchr("dnborx", opt)) { a = argc; break; }
+#ifdef STEREOPAR_BATCH_TEST_HOOKS
+        const char *value_options = "dnborx";
+#else
+        const char *value_options = "dnbor";
+#endif
+        if (a + 1 >= argc || !strchr(value_options, opt)) { a = argc; break; }
         const char *val = argv[++a];
         if (opt == 'd') device_list = val;
         else if (opt == 'o') out_dir = val;

@@ -72,8 +72,18 @@ def test_plan_options_struct_and_argument_checks():
     bad.struct_size = 3
     assert lib.sm_plan_create_ex(0, 64, 48, 30, 5, 0, 1, C.byref(bad), C.byref(h)) == capi.SM_ERR_ARG
     assert b"struct_size" in lib.sm_last_error()
-    bad.struct_size = 4096
+    bad.struct_size = -8
     assert lib.sm_plan_create_ex(0, 64, 48, 30, 5, 0, 1, C.byref(bad), C.byref(h)) == capi.SM_ERR_ARG
+    assert b"struct_size" in lib.sm_last_error()
+    # 0 ("no field set") and a LONGER struct (a caller built against a newer header: the known prefix is
+    # taken) pass the argument checks -- without a GPU the call then fails on the device, not on the struct
+    for size in (0, C.sizeof(capi.PlanOptions) + 64):
+        bad.struct_size = size
+        rc = lib.sm_plan_create_ex(0, 64, 48, 30, 5, 0, 1, C.byref(bad), C.byref(h))
+        assert rc == capi.SM_OK or b"struct_size" not in lib.sm_last_error()
+        if rc == capi.SM_OK:
+            lib.sm_plan_destroy(h)
+            h = C.c_void_p(0)
     assert lib.sm_plan_create_ex(0, 64, 48, 30, 5, 0, 1, None, None) == capi.SM_ERR_ARG
     assert not h.value
     csrc = ROOT / "stereomatching_amd" / "csrc"

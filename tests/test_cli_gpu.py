@@ -146,7 +146,10 @@ def test_stereopar_batch_failure_path_ends_cleanly(programs, tmp_path):  # noqa:
         write_pgm(tmp_path / f"r{j}.pgm", right)
         lines.append(f"l{j}.pgm r{j}.pgm")
     (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
-    exe = programs["timing"]["stereopar"].parent / "stereopar-batch"
+    exe = programs["timing"]["stereopar"].parent / "stereopar-batch-testhooks"     # (-DSTEREOPAR_BATCH_TEST_HOOKS)
+    product = programs["timing"]["stereopar"].parent / "stereopar-batch"
+    p = subprocess.run([str(product), "-x", "7", "list.txt"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and p.stderr.startswith("usage:")      # the product program has no such option
     for devices in ("0", "0,0"):
         p = subprocess.run([str(exe), "-d", devices, "-n", str(d), "-b", "1", "-r", "50", "-x", "7",
                             "list.txt", "0.15", "5"], cwd=tmp_path, capture_output=True, text=True, timeout=120)

@@ -134,3 +134,64 @@ def test_restatement_matches_the_reference_on_its_large_test_pairs(name, mode):
     web2 = oracle.fill_web_holes(web, p["times"])
     assert sha256_of(web2) == d["sha256"]["web-2"]
     assert sha256_of(oracle.draw_contour_map(web2, p["lines"])) == d["sha256"]["output-0"]
+
+
+def _cost_brute_force(left, right, num_shifts, square_width, mode, cost):
+    """The SAD / SSD mode written out directly from its definition (cost mode; no
+    reference exists: parity unpinned): c_d(x, y) = |L(x, y) - R(x + d, y)| or its square,
+    box sum over the (2 * (S / 2) + 1)^2 window, best = min over d, web = 1 + the FIRST d
+    reaching it.  Borders as the reference treats its edge images: toroidal wrap, or (ghost)
+    R = 0 beyond the right border and costs outside the image not counted.  Deliberately
+    shares nothing with oracle/stereo_oracle.c: plain numpy rolls / padded slices."""
+    L = left.astype(np.int64)
+    R = right.astype(np.int64)
+    h, w = L.shape
+    half = square_width // 2
+    vol = np.empty((num_shifts, h, w), np.int64)
+    for d in range(num_shifts):
+        if mode == "toroidal":
+            Rd = np.roll(R, -d, axis=1)
+        else:
+            Rd = np.zeros_like(R)
+            if d < w:
+                Rd[:, :w - d] = R[:, d:]
+        diff = L - Rd
+        c = diff * diff if cost == "ssd" else np.abs(diff)
+        if mode == "toroidal":
+            # taps may wrap more than once when the window is wider than the image
+            agg = np.zeros_like(c)
+            for sy in range(-half, half + 1):
+                for sx in range(-half, half + 1):
+                    agg += np.roll(np.roll(c, -sy, axis=0), -sx, axis=1)
+        else:
+            p = np.pad(c, half)
+            agg = np.zeros_like(c)
+            for sy in range(2 * half + 1):
+                for sx in range(2 * half + 1):
+                    agg += p[sy:sy + h, sx:sx + w]
+        vol[d] = agg
+    return vol.min(axis=0).astype(np.int32), (vol.argmin(axis=0) + 1).astype(np.int32)   # argmin: first wins
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("cost", ["sad", "ssd"])
+@pytest.mark.parametrize("w,h,d,sw,kind", [
+    (37, 23, 9, 5, "scene"),      # odd window
+    (40, 17, 16, 4, "scene"),     # even S rounds up to 5 x 5
+    (19, 31, 7, 0, "noise"),      # S = 0: a 1 x 1 window
+    (24, 9, 30, 9, "scene"),      # more shifts than columns: every ghost column past w - d reads 0
+    (12, 10, 5, 12, "noise"),     # the window as wide as the image (taps wrap onto themselves)
+    (33, 12, 8, 3, "flat"),       # constant images: every shift ties, the first must win
+])
+def test_cost_definition_matches_numpy_brute_force(mode, cost, w, h, d, sw, kind):
+    if kind == "flat":
+        left = np.full((h, w), 77, np.uint8)
+        right = np.full((h, w), 77, np.uint8)
+    else:
+        left, right = make_pair(w, h, d, seed=w * 7 + h * 3 + d, kind=kind)
+    best, web = oracle.cost_hot_path(left, right, d, sw, mode, cost)
+    rb, rw = _cost_brute_force(left, right, d, sw, mode, cost)
+    assert np.array_equal(best, rb), (mode, cost, "best")
+    assert np.array_equal(web, rw), (mode, cost, "web")
+    if kind == "flat" and mode == "toroidal":
+        assert (web == 1).all() and (best == 0).all()

@@ -132,6 +132,12 @@ def test_bench_starts_its_own_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
     assert out["dry_run"] is True and out["value"] == 0.0       # can never pass for a measurement
     assert out["ms_per_step"] >= 0.5
+    # the c4 object (SURVEY 8e's workload: 64 x 1080p, pair j -> rank j mod N, maps collected on rank 0)
+    # is part of every N > 1 line; the dry run exercises its sharding, barriers and collection
+    c4 = out["c4"]
+    assert c4["dry_run"] is True and c4["value"] == 0.0
+    assert c4["total_pairs"] == 64 and c4["pairs_per_rank"] == 32 and c4["maps_in_pair_order"] is True
+    assert c4["gather_ms"] > 0
 
 
 def test_bench_propagates_a_failing_rank():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # stereopar-batch's two host threads per device under ThreadSanitizer (the C host is CPU code;
 # the GPU side is untouched).  Build on the build box, run on the GPU box:
-#   gcc -std=gnu11 -g -O1 -fsanitize=thread -Iinclude -Ioracle -DNO_WRITES \
+#   gcc -std=gnu11 -g -O1 -fsanitize=thread -Iinclude -Ioracle -DNO_WRITES -DSTEREOPAR_BATCH_TEST_HOOKS \
 #       stereomatching_amd/host/stereopar_batch.c stereomatching_amd/host/image.c \
 #       -o timing/stereopar-batch-tsan -Lstereomatching_amd -lstereo_hip \
 #       -Wl,-rpath,'$ORIGIN/../stereomatching_amd' -lm -lpthread
