@@ -87,6 +87,28 @@ int sm_event_record(int device, void *event, void *stream);
 int sm_stream_wait_event(int device, void *stream, void *event);
 int sm_event_sync(int device, void *event);
 
+/* ---- result collection across the GPUs of one node: RCCL over xGMI ------- *
+ * New work (the reference drives one GPU and copies its map to the host: src/stereo.cu:402-403,
+ * src/image.cu:15-23).  The hot path shards with no data-path collective -- pair j -> device j mod n,
+ * SURVEY.md 8e -- and these calls are what BASELINE.json's north star names RCCL for: a broadcast of a
+ * parameter block and the collection of the result maps on one GPU.  ONE process drives the n devices
+ * (ncclCommInitAll; each call below enqueues the operations of all ranks inside one ncclGroupStart /
+ * ncclGroupEnd); rank r is devices[r], the root is rank 0.  All calls are asynchronous on the streams
+ * given (streams[r] on device r; NULL = every default stream).  librccl.so is loaded by sm_comm_create,
+ * not with this library.  (A host that wants its maps in HOST memory is better served by one download
+ * per device -- n PCIe links instead of one -- which is what host/stereopar_batch.c does.)            */
+typedef struct sm_comm sm_comm;
+int sm_comm_create(const int *devices, int n, sm_comm **out);     /* every device at most once */
+void sm_comm_destroy(sm_comm *comm);
+int sm_comm_size(const sm_comm *comm);
+/* bytes at d_buf[0] (device 0 of the communicator) -> d_buf[r] on every device r */
+int sm_broadcast(sm_comm *comm, void *const *d_buf, size_t bytes, void *const *streams);
+/* rank r contributes bytes[r] bytes at d_src[r]; the root receives them back to back, in rank order, at
+ * d_dst (its own share is a copy on its device; ranks with bytes[r] == 0 take no part): point-to-point
+ * ncclSend / ncclRecv, all in flight together.  The caller maps rank order to pair order (pair j -> rank
+ * j mod n: host/batch_index.h).                                                                       */
+int sm_gather_maps(sm_comm *comm, void *const *d_src, const size_t *bytes, void *d_dst, void *const *streams);
+
 /* ---- plan: geometry + private workspace for one image size ------------- *
  * num_shifts  = the reference's compile-time NUM_SHIFTS (src/stereo.c:6),
  *               here a run-time value, 1..65535
@@ -104,7 +126,9 @@ void sm_plan_destroy(sm_plan *plan);
  * apply to the kernel the plan uses is ignored (sm_plan_describe / sm_plan_geometry say what was
  * taken).  The library reads no environment variable.                                      */
 typedef struct sm_plan_options {
-    int struct_size;            /* sizeof(sm_plan_options) as the caller compiled it */
+    int struct_size;            /* sizeof(sm_plan_options) as the caller compiled it: a shorter (older) struct leaves the
+                                 * missing fields 0, of a longer (newer) one the fields this library knows are taken;
+                                 * 0 is read as "no field set" (so `sm_plan_options o = {0}` is valid) */
     int kernel_family;          /* 1 = the popcount kernels (general fallback) even where the bit-sliced one is built */
     int tile_h;                 /* match kernel: output rows per wave */
     int shifts_per_lane;        /* bit-sliced kernel: 8 or 16 */
@@ -121,6 +145,9 @@ typedef struct sm_plan_options {
                                  * 1 = the wave slot's parity, 2 = the parity of the workgroup's slot on its CU (the two
                                  * waves of a two-wave workgroup are then favoured together); 0 = the plan's choice */
     int priority_on_change;     /* bit-sliced kernel: 1 = s_setprio only when the wanted priority changes, 2 = once per row;
+                                 * 0 = the plan's choice */
+    int lane_merge;             /* bit-sliced kernel: how the lanes that split a word's shift range are merged:
+                                 * 1 = per row with DPP, 2 = through LDS every four rows (where >= 4 lanes share a word);
                                  * 0 = the plan's choice */
 } sm_plan_options;
 int sm_plan_create_ex(int device, int width, int height, int num_shifts, int square_width,
@@ -149,6 +176,14 @@ typedef struct sm_geometry {
 int sm_plan_geometry(const sm_plan *plan, sm_geometry *out);
 /* bytes of private device workspace */
 size_t sm_plan_workspace_bytes(const sm_plan *plan);
+/* Narrow result maps (sm_match_wta_typed / sm_run_typed with SM_WEB_U8 / SM_WEB_U16) of the kernels that
+ * have no narrow store path of their own -- every kernel but the bit-sliced one, see sm_plan_describe --
+ * go through an int32 staging map of max_pairs * W * H * 4 bytes (about 265 MB for 8 pairs at 4K).  It is
+ * NOT part of a new plan: a caller that only ever asks for int32 maps never pays for it.  This call
+ * allocates it (counted in sm_plan_workspace_bytes from then on); without it the first narrow request does,
+ * inside that call -- a hipMalloc, which synchronises the device, so callers that time their launches call
+ * this next to their own allocations.  A no-op for plans that do not need the map.  SM_ERR_NOMEM on failure. */
+int sm_plan_reserve_narrow(sm_plan *plan);
 
 /* ---- step 1: edges ------------------------------------------------------ *
  * replaces find_all_edges<<<>>> (src/stereo.cu:27-92, ghost twin

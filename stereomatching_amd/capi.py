@@ -52,7 +52,7 @@ class PlanOptions(C.Structure):
                 ("shifts_per_lane", C.c_int), ("workgroup_waves", C.c_int), ("no_two_wave_cap", C.c_int),
                 ("priority_pattern", C.c_uint), ("edge_kernel", C.c_int), ("timing_by_records", C.c_int),
                 ("cost_pixels_per_lane", C.c_int), ("cost_tile_h", C.c_int), ("cost_kernel", C.c_int),
-                ("priority_class", C.c_int), ("priority_on_change", C.c_int)]
+                ("priority_class", C.c_int), ("priority_on_change", C.c_int), ("lane_merge", C.c_int)]
 
     @classmethod
     def make(cls, **kw):
@@ -80,11 +80,17 @@ _SIGNATURES = {
     "sm_event_record": (_int, [_int, _vp, _vp]),
     "sm_stream_wait_event": (_int, [_int, _vp, _vp]),
     "sm_event_sync": (_int, [_int, _vp]),
+    "sm_comm_create": (_int, [_intp, _int, C.POINTER(_vp)]),
+    "sm_comm_destroy": (None, [_vp]),
+    "sm_comm_size": (_int, [_vp]),
+    "sm_broadcast": (_int, [_vp, C.POINTER(_vp), _sz, C.POINTER(_vp)]),
+    "sm_gather_maps": (_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _vp, C.POINTER(_vp)]),
     "sm_plan_create": (_int, [_int, _int, _int, _int, _int, _int, _int, C.POINTER(_vp)]),
     "sm_plan_create_ex": (_int, [_int, _int, _int, _int, _int, _int, _int, C.POINTER(PlanOptions), C.POINTER(_vp)]),
     "sm_plan_destroy": (None, [_vp]),
     "sm_plan_describe": (C.c_char_p, [_vp]),
     "sm_plan_workspace_bytes": (_sz, [_vp]),
+    "sm_plan_reserve_narrow": (_int, [_vp]),
     "sm_plan_geometry": (_int, [_vp, C.POINTER(Geometry)]),
     "sm_find_edges": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp]),
     "sm_load_edges": (_int, [_vp, _vp, _vp, _int, _vp]),

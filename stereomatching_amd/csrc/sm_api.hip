@@ -349,7 +349,9 @@ __global__ __launch_bounds__(256) void k_edges_ext4(const u8 *__restrict__ src_l
     const int ye0 = STACKED ? (blockIdx.y * 4 + (tid >> 6)) * R : blockIdx.y * R;
     if (STACKED && ye0 >= g.ext_rows) return;             // the round-up of the strips (wave-uniform)
     // columns no valid output pixel can reach (the match kernel's tile round-up; for the left image
-    // also the shift range): left as they are -- zero since the plan was created (wave-uniform)
+    // also the shift range): left as they are (wave-uniform).  Zero since the plan was created, or -- after an
+    // sm_load_edges, whose k_pack_ext writes every ext column -- stale content of that call: either way no stored
+    // output pixel reads them (tests: sm_load_edges, then sm_find_edges and the match launch on one plan)
     if (((xe - 4 * lane) >> 5) >= ((blockIdx.z & 1) ? g.edge_words_r : g.edge_words_l)) return;
     const int pair = blockIdx.z >> 1, side = blockIdx.z & 1;
     const size_t img = (size_t)pair * g.w * g.h;
@@ -847,7 +849,9 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
                                  int border, int max_pairs, const sm_plan_options *options, sm_plan **out)
 {
     if (!out) return sm_fail(SM_ERR_ARG, "sm_plan_create: out is NULL");
-    if (options && (options->struct_size < (int)sizeof(int) || options->struct_size > (int)sizeof(sm_plan_options)))
+    // struct_size: 0 = "nothing but the size field" (an all-zero struct is the plan's own choice throughout);
+    // a LARGER struct comes from a caller built against a newer header: the prefix this library knows is taken
+    if (options && (options->struct_size < 0 || (options->struct_size > 0 && options->struct_size < (int)sizeof(int))))
         return sm_fail(SM_ERR_ARG, "sm_plan_create_ex: options->struct_size %d is not that of a sm_plan_options "
                        "(this library: %d bytes)", options->struct_size, (int)sizeof(sm_plan_options));
     *out = nullptr;
@@ -875,7 +879,9 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
     p->width = width; p->height = height;
     p->num_shifts = num_shifts; p->square_width = square_width;
     p->border = border; p->max_pairs = max_pairs;
-    if (options) memcpy(&p->opt, options, (size_t)options->struct_size);     // a shorter (older) struct: the rest stays 0
+    if (options && options->struct_size > 0)      // a shorter (older) struct: the rest stays 0; a longer one: the known prefix
+        memcpy(&p->opt, options, std::min((size_t)options->struct_size, sizeof(sm_plan_options)));
+    p->opt.struct_size = (int)sizeof(sm_plan_options);
     int rc = sm_match_configure(p);
     if (rc) { free(p); return rc; }
     p->g.web_bytes = 4;
@@ -893,10 +899,9 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_flags, 4 * sizeof(i32), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemset(p->d_ext, 0, p->ext_bytes);
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(i32));
-    // kernels without a narrow store path write narrow maps through an int32 staging map: part of
-    // the workspace, allocated here (a hipMalloc inside a launch call would synchronise the device)
-    if (e == hipSuccess && p->kernel != SM_KERNEL_BS)
-        e = hipMalloc((void **)&p->d_web_tmp, (size_t)max_pairs * width * height * sizeof(i32));
+    // (kernels without a narrow store path write narrow maps through an int32 staging map,
+    // max_pairs * W * H * 4 bytes: NOT allocated here -- a plan whose caller only ever asks for
+    // int32 maps must not pay for it -- but by sm_plan_reserve_narrow, or by the first narrow request)
     if (e != hipSuccess) {
         for (int b = 0; b < 2; b++) {
             if (p->d_ext_buf[b]) (void)hipFree(p->d_ext_buf[b]);
@@ -934,6 +939,27 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
     }
     *out = p;
     return SM_OK;
+}
+
+// the int32 staging map of narrow results for the kernels that have no narrow store path
+static int reserve_narrow(sm_plan *plan, const char *me)
+{
+    if (plan->d_web_tmp || plan->kernel == SM_KERNEL_BS) return SM_OK;
+    const size_t bytes = (size_t)plan->max_pairs * plan->width * plan->height * sizeof(i32);
+    const hipError_t e = hipMalloc((void **)&plan->d_web_tmp, bytes);
+    if (e != hipSuccess) {
+        plan->d_web_tmp = nullptr;
+        return sm_fail(e == hipErrorOutOfMemory ? SM_ERR_NOMEM : SM_ERR_HIP,
+                       "%s: %zu bytes for the int32 staging map of narrow results: %s", me, bytes, hipGetErrorString(e));
+    }
+    return SM_OK;
+}
+
+extern "C" int sm_plan_reserve_narrow(sm_plan *plan)
+{
+    if (!plan) return sm_fail(SM_ERR_ARG, "sm_plan_reserve_narrow: plan is NULL");
+    SM_TRY(use_device(plan->device));
+    return reserve_narrow(plan, "sm_plan_reserve_narrow");
 }
 
 extern "C" void sm_plan_destroy(sm_plan *plan)
@@ -1164,7 +1190,13 @@ extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int
     // kernels without a narrow store path: int32 into the plan's staging map (allocated with the
     // plan), then narrow.  ONE staging map per plan: see the threading note in stereo_hip.h
     const bool via_tmp = web_bytes != 4 && plan->kernel != SM_KERNEL_BS;
-    if (via_tmp) d_web = plan->d_web_tmp;
+    if (via_tmp) {
+        if (!plan->d_web_tmp) {         // the first narrow request on such a plan (sm_plan_reserve_narrow keeps
+            SM_TRY(use_device(plan->device));      // this allocation, which synchronises the device, out of a timed path)
+            SM_TRY(reserve_narrow(plan, me));
+        }
+        d_web = plan->d_web_tmp;
+    }
     if (pairs > plan->pairs_loaded)
         return sm_fail(SM_ERR_ARG, "%s: %d pairs requested but edges of only %d are loaded "
                        "(call sm_find_edges or sm_load_edges first)", me, pairs, plan->pairs_loaded);

@@ -294,7 +294,8 @@ const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_le
     else if (nq <= 9) { nql = 9; px = 4; }
     else if (nq <= 17) { nql = 17; px = 4; }
     else { nql = 33; px = 2; }
-    if (plan->opt.cost_pixels_per_lane && nql == 17) px = plan->opt.cost_pixels_per_lane;
+    // (an explicit choice applies where both widths are built; anything else is ignored, not launched)
+    if ((plan->opt.cost_pixels_per_lane == 2 || plan->opt.cost_pixels_per_lane == 4) && nql == 17) px = plan->opt.cost_pixels_per_lane;
     g.nl = 1; g.log2nl = 0;
     while (g.nl * nql < nq) { g.nl <<= 1; g.log2nl++; }
     g.tw = 4 * px * (16 / g.nl);
@@ -323,7 +324,10 @@ const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_le
         if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
     }
     if (!best_th) return nullptr;
-    if (plan->opt.cost_tile_h > 0) best_th = plan->opt.cost_tile_h;
+    if (plan->opt.cost_tile_h > 0) {         // an explicit tile height, clamped to what a workgroup's LDS holds
+        best_th = plan->opt.cost_tile_h;
+        while (best_th > 1 && (size_t)(best_th + n - 1) * (g.lrow + g.rrow) + 2 * (size_t)g.rrow > 64 * 1024) best_th--;
+    }
     g.tile_h = best_th < g.h ? best_th : g.h;
     g.tiles_y = (g.h + g.tile_h - 1) / g.tile_h;
     g.nsr = g.tile_h + n - 1;

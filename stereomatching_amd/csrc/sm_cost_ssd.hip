@@ -320,7 +320,10 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
         if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
     }
     if (!best_th) return nullptr;
-    if (plan->opt.cost_tile_h > 0) best_th = plan->opt.cost_tile_h;
+    if (plan->opt.cost_tile_h > 0) {         // an explicit tile height, clamped to what a workgroup's LDS holds
+        best_th = plan->opt.cost_tile_h;
+        while (best_th > 1 && (size_t)(best_th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)g.rrow > 64 * 1024) best_th--;
+    }
     g.tile_h = best_th < g.h ? best_th : g.h;
     g.tiles_y = (g.h + g.tile_h - 1) / g.tile_h;
     g.nsr = g.tile_h + n - 1;

@@ -61,6 +61,10 @@ struct MatchGeom {
     unsigned prio_pattern;   // bit-sliced kernel: the time-sliced priority schedule (sm_match_bs_kernel.h)
     int prio_shift;          // ... the HW_ID bit that tells a SIMD's two waves apart: 0 wave slot, 16 workgroup slot (TG_ID)
     int prio_on_change;      // ... s_setprio only when the wanted priority changes (else once per row)
+    int xmerge;          // bit-sliced kernel: the shift lanes of a word are merged through LDS every 4 rows (nl >= 4)
+    int xm_off;          // ... word offset in LDS where the exchange slots of a two-wave workgroup meet and the
+                         //     merge buffers lie (wave 0's from here up, wave 1's from here down; a lone wave's from here up)
+    int xm_words;        // ... words of one wave's merge buffer
     int web_bytes;       // bytes per element of the web map of THIS launch: 4 (int32), 2, 1
     // ext words per row that can reach a valid output pixel (left image: columns up to W - 1 + half;
     // right: + D - 1 more); the edge kernels compute no others (the tile round-up stays zero)

@@ -505,6 +505,7 @@ int sm_match_configure(sm_plan *plan)
         g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = g.ds = 0;
         g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = g.cap2 = g.duo = 0;
         g.prio_pattern = 0;
+        g.xmerge = g.xm_off = g.xm_words = 0;
         g.prio_shift = 0;
         g.prio_on_change = 0;
         g.edge_words_l = g.edge_words_r = g.ext_words;
@@ -570,10 +571,32 @@ int sm_match_configure(sm_plan *plan)
         int sb = 0;
         while ((1 << sb) <= o.n * o.n) sb++;
         const int rows_per_wg = duo ? 2 : 1;
-        auto lds_of = [&](int th) {
-            const int staged = (rows_per_wg * th + o.n - 1) * rows_words * 4;
-            return duo ? ((staged + 7) & ~7) + ds * sb * 256 : staged;
+        // lane merge through LDS (k_match_bs, g.xmerge): where at least 4 lanes share a word; per wave
+        // 4 x NPG blocks of 1 KB behind the staged rows, in a two-wave workgroup over the exchange slots
+        const int ab = ds == 16 ? 4 : 3;
+        const int npg = (sb + ab + 3) / 4;
+        // Taken where it pays: 16 shifts per lane and at least 8 lanes per word (C3: -4.3 % of the launch's
+        // VALU instructions, -3 % of its time; C5: -10 %).  With 4 lanes per word there are only two DPP levels
+        // to save and the batch's bursts of stores cost more than that (C4 x 8: +5 %); the 8-shifts-per-lane
+        // builds run 4- to 9-row tiles, whose last batch is mostly empty.  lane_merge = 2 forces it wherever
+        // it is possible (tests, measurements), 1 forbids it.  profiles/r04/ab_lane_merge.txt
+        const bool xm_possible = bs && o.log2nl >= 2 && o.nl <= 32;
+        o.xmerge = xm_possible && plan->opt.lane_merge != 1 &&
+                   (plan->opt.lane_merge == 2 || (ds == 16 && o.log2nl >= 3));
+        const int mb_words = o.xmerge ? npg * 1024 : 0;
+        auto lds_words = [&](int th, int &xm_off) {
+            const int staged = ((rows_per_wg * th + o.n - 1) * rows_words + 3) & ~3;
+            if (!bs) { xm_off = 0; return (rows_per_wg * th + o.n - 1) * rows_words; }
+            if (duo) {
+                const int slot = ds * sb * 32;                    // words of one exchange slot
+                const int half = std::max(slot, mb_words);
+                xm_off = staged + half;
+                return staged + 2 * half;
+            }
+            xm_off = staged;
+            return staged + mb_words;
         };
+        auto lds_of = [&](int th) { int off; return lds_words(th, off) * 4; };
         int th = 0;
         double best_cost = 0;
         for (int c = 2; c <= 256; c++) {
@@ -606,7 +629,8 @@ int sm_match_configure(sm_plan *plan)
         o.tile_h = th;
         o.tiles_y = ceil_div(H, rows_per_wg * th);
         o.nsr = rows_per_wg * th + o.n - 1;
-        o.lds_bytes = lds_of(th);
+        o.lds_bytes = lds_words(th, o.xm_off) * 4;
+        o.xm_words = mb_words;
         // A grid that fits the chip in one round must also be SPREAD evenly: where the
         // registers allow more resident workgroups than the round needs (7x7: 3 waves
         // per SIMD, 2 needed) the dispatcher may stack 3 waves on some SIMDs and leave
@@ -708,18 +732,26 @@ int sm_match_configure(sm_plan *plan)
     // of match launches -- and LOSES 5 % in the real step, where it follows the edge kernel and its workgroups
     // find other slots (tools/sustained_ab.sh, profiles/r03/sustained_ab.txt): an option for tuning, not the default
     g.prio_shift = 0;
-    if (plan->opt.priority_class) g.prio_shift = plan->opt.priority_class == 2 ? 16 : 0;   // tuning
+    if (plan->opt.priority_class == 2) {
+        // the workgroup's slot tells a SIMD's two waves apart only for two-wave workgroups of a launch that fits
+        // the chip in ONE round (later workgroups land in whatever slot is free): anything else keeps the wave slot
+        const long long tiles = (long long)g.tiles_x * g.tiles_y * plan->max_pairs;
+        if (bs && g.duo && tiles <= 4ll * cus) g.prio_shift = 16;                           // tuning
+    }
     g.prio_on_change = plan->opt.priority_on_change == 1;                                 // tuning (default: once per row)
 
     snprintf(plan->describe, sizeof plan->describe,
              "%s (n=%d, D=%d, %s): tile %dx%d px, %d threads "
-             "(%d runs x %d shift-lanes of %d), grid %dx%d, LDS %d B/wg%s%s, ext %dx%d words",
+             "(%d runs x %d shift-lanes of %d), grid %dx%d, LDS %d B/wg%s%s%s, ext %dx%d words",
              bs ? "bit-sliced kernel" : kernel == SM_KERNEL_A ? "tiled kernel A"
                 : kernel == SM_KERNEL_B ? "tiled kernel B" : "tiled kernel C",
              g.n, D, ghost ? "ghost" : "toroidal",
              g.tw, g.duo ? 2 * g.tile_h : g.tile_h, g.threads, g.runs, g.nl, g.ds, g.tiles_x, g.tiles_y, g.lds_bytes,
              g.duo ? ", two-wave workgroups" : g.cap2 ? ", 2 waves/SIMD variant" : "",
-             g.prio_shift ? " favoured by workgroup slot" : "", g.ext_words, g.ext_rows);
+             g.xmerge ? ", lanes merged through LDS" : "",
+             g.prio_shift ? ", favoured by workgroup slot"
+                          : plan->opt.priority_class == 2 ? ", priority class 2 not applicable: by wave slot" : "",
+             g.ext_words, g.ext_rows);
     return SM_OK;
 }
 

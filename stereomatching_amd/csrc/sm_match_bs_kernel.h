@@ -116,6 +116,10 @@ __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh)
 #ifndef SM_BS_PREFETCH
 #define SM_BS_PREFETCH 1
 #endif
+// the shift lanes of a word merged through LDS every four rows (g.xmerge) instead of per row with DPP
+#ifndef SM_BS_XMERGE
+#define SM_BS_XMERGE 1
+#endif
 typedef unsigned long long u64;
 struct RawRow { u64 l01; u32 l2; u64 r01, r23; };      // 3 left words, 4 right words
 struct RawCentre { u32 l; u64 r01; u32 r2; };          // centre word, 3 right words
@@ -779,7 +783,9 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
         constexpr int DH = DS / 2, XP = DH * SB / 2;
         static_assert(DS % 2 == 0 && (DH * SB) % 2 == 0, "exchange halves");
         typedef u32 v2u __attribute__((ext_vector_type(2)));
-        v2u *xq = reinterpret_cast<v2u *>(lds + ((nsr * (plw + prw) + 1) & ~1)) + tid;
+        // (the two slots end / begin at word g.xm_off: behind them -- and over them, once the warm-up
+        // is done -- lie the buffers of the lane merge, wave w's over the slot that wave w reads LAST)
+        v2u *xq = reinterpret_cast<v2u *>(lds + g.xm_off - XP * 128) + tid;
         auto exchange = [&](auto own_tag) {
             constexpr int OWN = decltype(own_tag)::value, OTH = 1 - OWN;
             v2u *slot_own = xq + OWN * XP * 64, *slot_oth = xq + OTH * XP * 64;
@@ -831,6 +837,14 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
     SM_SLICE_READ();
     SM_STAMP(2);
 
+#if SM_BS_XMERGE
+    // lane merge through LDS (see the row loop): this wave's buffer of g.xm_words words = 4 x NPG blocks of 1 KB.  In a two-wave
+    // workgroup wave 0's begins at word g.xm_off (over exchange slot 1, which wave 0 is the last to read) and
+    // wave 1's ends there (over slot 0); a lone wave's begins there.
+    u32 *xm_base = lds + g.xm_off - ((DUO && wv) ? g.xm_words : 0);
+    u32 *xm_wbase = xm_base + (s & 3) * ((SB + AB + 3) / 4) * 256;
+    const u32 xm_wunit = (u32)(wi * (g.nl >> 2) + (s >> 2) + 2 * (s & 3));
+#endif
 #if SM_BS_PREFETCH
     // byte addresses (LDS offsets: the low half of the flat address) of this lane's words
     // in staged row 0, and the row strides; the reads of iteration t + 1 are issued while
@@ -987,40 +1001,30 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
         }
 #endif
 
-        // ---- merge the nl lanes of this word: lower count wins, on a tie the lane
-        // with the higher shifts (partner's bit K of the lane index set)
-#define SM_MERGE(K)                                                                    \
-        if (g.nl > (1 << K)) {                                                         \
-            u32 pb[SB], pa[AB + K];                                                    \
-            _Pragma("unroll") for (int k = 0; k < SB; k++) pb[k] = from_partner<K>(B[k]);      \
-            _Pragma("unroll") for (int k = 0; k < AB + K; k++) pa[k] = from_partner<K>(arg[k]); \
-            SM_PIN(); SM_SYNC(1);                                                      \
-            const u32 mine_high = (s >> K) & 1 ? 0xffffffffu : 0u;                     \
-            u32 bw = mine_high;          /* borrow-in 1: partner - mine - 1 < 0 <=> partner <= mine */ \
-            bw = ~bw;                    /* partner is the high one iff I am not */   \
-            _Pragma("unroll") for (int k = 0; k < SB; k++) bw = bop<BOP_BORROW>(pb[k], B[k], bw); \
-            const u32 take = bw;                                                       \
-            _Pragma("unroll") for (int k = 0; k < SB; k++) B[k] = bop<BOP_SEL>(take, pb[k], B[k]); \
-            _Pragma("unroll") for (int k = 0; k < AB + K; k++) arg[k] = bop<BOP_SEL>(take, pa[k], arg[k]); \
-            arg[AB + K] = take ^ mine_high;   /* partner's bit K = ~mine */          \
-        }
-        SM_MERGE(0) SM_MERGE(1) SM_MERGE(2) SM_MERGE(3) SM_MERGE(4) SM_MERGE(5)
-#undef SM_MERGE
-
-        // ---- planes -> integers.  After the merge all nl lanes of a word hold the
-        // same planes; lane s converts pixels [s*per, s*per + per), per = 32/nl, in
-        // chunks of up to 4.  nib = the chunk's bits of a plane; nib * 0x204081 puts
-        // copy j of the nibble at bit 7j, so bit 8q holds pixel q's bit: & 0x01010101
-        // leaves one byte per pixel, and byte lanes then add up the planes.
-        if (y < g.h) {
-            const int per = 32 >> g.log2nl;            // nl <= 32
+        // ---- planes -> integers, for `per` pixels of the word at image column xw, row yy, starting at
+        // pixel pfirst of the word, in chunks of up to 4.  nib = the chunk's bits of a plane;
+        // nib * 0x204081 puts copy j of the nibble at bit 7j, so bit 8q holds pixel q's bit:
+        // & 0x01010101 leaves one byte per pixel, and byte lanes then add up the planes.
+        auto emit_pixels = [&](u32 (&B)[SB], u32 (&arg)[ABMAX], int xw, int yy, int pfirst, int per) {
             const int cw = per < 4 ? per : 4;          // pixels per chunk
             const u32 cmask = (1u << cw) - 1u;
             u32 allone = B[0];
 #pragma unroll
             for (int k = 1; k < SB; k++) allone &= B[k];
+#if SM_BS_XMERGE
+            // "no shift matched" (all planes of the count set) -> web = D: folded in on the PLANES,
+            // 32 pixels per operation, instead of a select per pixel (bit k of D - 1 for all lanes)
+            u32 dm1 = (u32)(g.D - 1);
+            asm volatile("" : "+s"(dm1));       // (re-made here from one SGPR: hoisted out of the row loop the ABMAX
+                                                // masks cost SGPR spills, i.e. v_readlane in front of every use)
+#pragma unroll
+            for (int k = 0; k < ABMAX; k++) {
+                if (k >= AB && k >= AB + g.log2nl) continue;   // uniform: planes no merge level set
+                arg[k] = bop<BOP_SEL>(allone, (u32)-(i32)((dm1 >> k) & 1u), arg[k]);
+            }
+#endif
             for (int c = 0; c < per; c += 4) {
-                const int p0 = s * per + c;
+                const int p0 = pfirst + c;
                 u32 bb = 0, bhi = 0, alo = 0, ahi = 0;
                 if (best) {                          // uniform: the counts are wanted at all
 #pragma unroll
@@ -1042,17 +1046,21 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
                     const bool no = (none >> (8 * q)) & 1u;
                     int taps = N * N;
                     if (GHOST) {
-                        const int x = x0 + p0 + q;
+                        const int x = xw + p0 + q;
                         const int cols = min(g.w - 1, x + HALF) - max(0, x - HALF) + 1;
-                        const int rws = min(g.h - 1, y + HALF) - max(0, y - HALF) + 1;
+                        const int rws = min(g.h - 1, yy + HALF) - max(0, yy - HALF) + 1;
                         taps = cols * rws;
                     }
                     const i32 a = (i32)(((alo >> (8 * q)) & 255u) | (((ahi >> (8 * q)) & 255u) << 8));
+#if SM_BS_XMERGE
+                    wv[q] = a + 1;
+#else
                     wv[q] = no ? g.D : a + 1;
+#endif
                     bv[q] = no ? 0 : taps - (i32)(((bb >> (8 * q)) & 255u) | (((bhi >> (8 * q)) & 255u) << 8));
                 }
-                const int x = x0 + p0;
-                const size_t o = ((size_t)pair * g.h + y) * g.w + x;
+                const int x = xw + p0;
+                const size_t o = ((size_t)pair * g.h + yy) * g.w + x;
                 const bool vec = cw == 4 && g.vec_ok && x + 4 <= g.w;
                 // streaming stores: the maps are written once and never read here
                 if (g.web_bytes == 4) {
@@ -1100,7 +1108,141 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
                     }
                 }
             }
+        };
+
+        // lanes `me` and me ^ (1 << K) hold candidates of the same pixels: lower count wins, on a tie
+        // the lane with the higher shifts (bit K of `me` set); the winner's bit K becomes plane NA
+#define SM_MERGE(K, me, NA)                                                            \
+        {                                                                              \
+            u32 pb[SB], pa[NA];                                                        \
+            _Pragma("unroll") for (int k = 0; k < SB; k++) pb[k] = from_partner<K>(B[k]);      \
+            _Pragma("unroll") for (int k = 0; k < NA; k++) pa[k] = from_partner<K>(arg[k]);    \
+            SM_PIN(); SM_SYNC(1);                                                      \
+            const u32 mine_high = ((me) >> K) & 1 ? 0xffffffffu : 0u;                  \
+            u32 bw = mine_high;          /* borrow-in 1: partner - mine - 1 < 0 <=> partner <= mine */ \
+            bw = ~bw;                    /* partner is the high one iff I am not */   \
+            _Pragma("unroll") for (int k = 0; k < SB; k++) bw = bop<BOP_BORROW>(pb[k], B[k], bw); \
+            const u32 take = bw;                                                       \
+            _Pragma("unroll") for (int k = 0; k < SB; k++) B[k] = bop<BOP_SEL>(take, pb[k], B[k]); \
+            _Pragma("unroll") for (int k = 0; k < NA; k++) arg[k] = bop<BOP_SEL>(take, pa[k], arg[k]); \
+            arg[NA] = take ^ mine_high;   /* partner's bit K = ~mine */              \
         }
+#if SM_BS_XMERGE
+        if (g.xmerge) {
+            // ---- THE NL LANES OF A WORD ARE MERGED THROUGH LDS, FOUR ROWS AT A TIME.  Merging them per
+            // row with DPP costs log2(nl) full compare-and-select levels per lane and row (~105 VALU
+            // instructions of 1640 at C3, 36 of them half-rate DPP moves; measured by leaving them out:
+            // -7 % of the launch).  Instead every lane hands the planes of its candidate over (NPG
+            // 16-byte stores per row), and after four rows the 4 * 64 / nl (row, word) items of the batch
+            // are dealt to the 64 lanes, nl / 4 lanes per item: each scans FOUR candidates in ascending
+            // shift order (<=: the later of equal counts wins) and only log2(nl) - 2 DPP levels remain,
+            // once per four rows; lane `sub` of an item then turns 128 / nl pixels into integers.
+            // Layout: block (j, pg) of 64 x 16 bytes holds plane group pg of the candidates of the
+            // shift lanes s = 4 * sub + j; candidate (row r, word wi, sub) sits at unit
+            // (16 r + wi * LPI + sub + 2 j) & 63 -- a reader lane l reads unit (l + 2 j) & 63 of each
+            // block (one aligned 1 KB run per read: conflict-free), a writer's 8 contiguous lanes hit 8
+            // distinct 16-byte columns of the 32 store banks.
+            constexpr int NPL = SB + AB, NPG = (NPL + 3) / 4;
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) const volatile v4u lds_vv4;
+            const u32 xm_lds = (u32)(uintptr_t)xm_base;          // LDS offset: the low half of the flat address
+            const int r = t & 3;
+            {
+                u32 pl[4 * NPG];
+#pragma unroll
+                for (int k = 0; k < 4 * NPG; k++) pl[k] = k < SB ? B[k] : (k < NPL ? arg[k - SB] : 0u);
+                const u32 unit = (xm_wunit + 16u * (u32)r) & 63u;
+#pragma unroll
+                for (int pg = 0; pg < NPG; pg++) {
+                    const v4u v = {pl[4 * pg], pl[4 * pg + 1], pl[4 * pg + 2], pl[4 * pg + 3]};
+                    *reinterpret_cast<v4u *>(xm_wbase + pg * 256 + unit * 4) = v;
+                }
+            }
+            if (r == 3 || t + 1 >= rows_out) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // reader role: item (rr, wr), sub-lane `sub` of its LPI lanes
+                const int lpi = g.nl >> 2, l2lpi = g.log2nl - 2;
+                const int rr = tid >> 4, wr = (tid & 15) >> l2lpi, sub = tid & (lpi - 1);
+                u32 Bm[SB], am[ABMAX];
+#pragma unroll
+                for (int k = 0; k < ABMAX; k++) am[k] = 0;
+                // all 4 x NPG reads are issued before the first candidate is looked at (volatile: they stay
+                // where they are written, as the row prefetch above): ONE exposed LDS latency per batch --
+                // left to itself the compiler reads candidate by candidate and the wave waits seven times
+                v4u ev[4][NPG];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u32 unit = ((u32)tid + 2u * j) & 63u;
+#pragma unroll
+                    for (int pg = 0; pg < NPG; pg++)
+                        ev[j][pg] = *(lds_vv4 *)(uintptr_t)(xm_lds + 4u * (u32)((j * NPG + pg) * 256) + 16u * unit);
+                }
+                SM_PIN();
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    u32 e[4 * NPG];
+#pragma unroll
+                    for (int pg = 0; pg < NPG; pg++) {
+                        const v4u v = ev[j][pg];
+                        e[4 * pg] = v.x; e[4 * pg + 1] = v.y; e[4 * pg + 2] = v.z; e[4 * pg + 3] = v.w;
+                    }
+                    if (j == 0) {
+#pragma unroll
+                        for (int k = 0; k < SB; k++) Bm[k] = e[k];
+#pragma unroll
+                        for (int k = 0; k < AB; k++) am[k] = e[SB + k];
+                    } else {
+                        u32 bw = 0xffffffffu;      // borrow-in 1: candidate - mine - 1 < 0 <=> candidate <= mine
+#pragma unroll
+                        for (int k = 0; k < SB; k++) bw = bop<BOP_BORROW>(e[k], Bm[k], bw);
+                        const u32 take = bw;
+#pragma unroll
+                        for (int k = 0; k < SB; k++) Bm[k] = bop<BOP_SEL>(take, e[k], Bm[k]);
+#pragma unroll
+                        for (int k = 0; k < AB; k++) am[k] = bop<BOP_SEL>(take, e[SB + k], am[k]);
+                        if (j & 1) am[AB] |= take; else am[AB] = bop<BOP_ANDN>(take, am[AB], 0u);
+                        if (j & 2) am[AB + 1] |= take; else am[AB + 1] = bop<BOP_ANDN>(take, am[AB + 1], 0u);
+                    }
+                }
+                {
+                    u32 (&B)[SB] = Bm;
+                    u32 (&arg)[ABMAX] = am;
+                    if (lpi > 1) SM_MERGE(0, sub, AB + 2)
+                    if (lpi > 2) SM_MERGE(1, sub, AB + 3)
+                    if (lpi > 4) SM_MERGE(2, sub, AB + 4)
+                }
+                const int tt = t - r + rr;                      // the item's output row of this wave
+                const int yy = y0 + sgn * tt;
+                // (Each lane stores 16-byte pieces of its own pixels, 64 bytes apart at nl = 8: routing the
+                // integers through LDS so that every store instruction writes whole rows was built and measured --
+                // no better at C3 / C5 (90.6 vs 89.5 us), the extra LDS round trip costs what the contiguous
+                // stores gain; the store flavour matters far more: with `nt` instead of `sc1` such pieces cost a
+                // factor 2.3 at 8 x 1080p.  profiles/r04/ab_store_flavour.txt, ab_lane_merge*.txt)
+                if (rr <= r && yy < g.h && yy >= 0) {
+                    const int per = 32 >> l2lpi;
+                    emit_pixels(Bm, am, tx0 + 32 * wr, yy, sub * per, per);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else
+#endif
+        {
+            // ---- merge the nl lanes of this word per row (DPP; ds_bpermute beyond 16 lanes)
+            if (g.nl > 1) SM_MERGE(0, s, AB)
+            if (g.nl > 2) SM_MERGE(1, s, AB + 1)
+            if (g.nl > 4) SM_MERGE(2, s, AB + 2)
+            if (g.nl > 8) SM_MERGE(3, s, AB + 3)
+            if (g.nl > 16) SM_MERGE(4, s, AB + 4)
+            if (g.nl > 32) SM_MERGE(5, s, AB + 5)
+            // After the merge all nl lanes of a word hold the same planes; lane s converts
+            // pixels [s * per, s * per + per), per = 32 / nl
+            if (y < g.h) {
+                const int per = 32 >> g.log2nl;            // nl <= 32
+                emit_pixels(B, arg, x0, y, s * per, per);
+            }
+        }
+#undef SM_MERGE
 
         // ---- slide the window down: staged row t + N - 1 in, staged row t - 1 out
         SM_SYNC(1);

@@ -501,6 +501,47 @@ def test_every_built_kernel_matches_oracle(hip, n, ds, shape, fulld, mode):
     assert np.array_equal(best[0], obest), desc
 
 
+LDS_MERGE = dict(lane_merge=2)
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("shape,tile_h", [(ONE_WAVE, 4), (ONE_WAVE, 6), (TWO_WAVES, 4), (TWO_WAVES, 9)])
+@pytest.mark.parametrize("nl", [4, 8, 16, 32])
+@pytest.mark.parametrize("n,ds", BUILT_BS)
+def test_lane_merge_through_lds_matches_oracle(hip, n, ds, nl, shape, tile_h, mode):
+    """k_match_bs with the lanes of a word merged through LDS every four rows (g.xmerge; the plan's choice at
+    C3 / C5, forced here with lane_merge = 2 on EVERY built window x shifts per lane): 4, 8, 16 and 32 lanes
+    per word (1, 2, 4, 8 lanes per item of a batch: no DPP level, one, two, three), shift ranges that fill the
+    lanes and that do not, tiles whose last batch is whole (4 rows) and partial (6 = 4 + 2, 9 = 2 x 4 + 1),
+    an image width that is not a multiple of 4 (scalar stores) and one that is, both borders, best map too."""
+    fulld = (n + nl + tile_h) % 2 == 0
+    d = nl * ds if fulld else nl * ds - 3
+    w, h = (152 if (n + nl) % 4 < 2 else 150), n + 13
+    le, re = rand_edges(w, h, seed=n * 100 + ds + nl)
+    best, web, desc = hip_hot_path(hip, le, re, d, n, mode,
+                                   options=dict(shape, shifts_per_lane=ds, tile_h=tile_h, **LDS_MERGE))
+    assert "lanes merged through LDS" in desc and f"{nl} shift-lanes of {ds})" in desc, desc
+    obest, oweb = oracle.hot_path(le, re, d, n, mode)
+    assert np.array_equal(web[0], oweb), desc
+    assert np.array_equal(best[0], obest), desc
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.uint16])
+def test_lane_merge_through_lds_narrow_maps(hip, dtype):
+    """... and its narrow result maps (dword / qword stores of 4 pixels), web only"""
+    w, h, d, sw = 512, 37, 128, 9
+    le, re = rand_edges(w, h, seed=3)
+    _, oweb = oracle.hot_path(le, re, d, sw, "toroidal")
+    for opts in (LDS_MERGE, dict(lane_merge=1)):
+        plan = hip.StereoPlan(w, h, d, sw, "toroidal", options=opts)
+        assert ("lanes merged through LDS" in plan.describe()) == (opts is LDS_MERGE)
+        plan.load_edges(dev(le), dev(re))
+        webn, _ = plan.match_wta(1, want_best=False, web_dtype=dtype)
+        torch.cuda.synchronize()
+        assert np.array_equal(host(webn.to(torch.int32))[0], oweb), plan.describe()
+        plan.close()
+
+
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
 def test_one_pixel_edge_kernel(hip, mode):
     left, right = make_pair(128, 66, 16, seed=4)
@@ -909,9 +950,27 @@ def test_soak_random_pipelines(hip):
         imgs = [make_pair(w, h, d, seed=int(rng.integers(1 << 30)), kind=kind) for _ in range(pairs)]
         left = np.stack([p[0] for p in imgs]); right = np.stack([p[1] for p in imgs])
         plan = hip.StereoPlan(w, h, d, sw, mode, max_pairs=pairs)
-        web, best = plan.run(dev(left), dev(right), thr, want_best=True)
+        pipelined = int(rng.integers(0, 3))              # 0 off, 1 on, 2 on + inputs ordered behind the stream
+        if pipelined:
+            # the two internal lanes under the soak -- consecutive calls with alternating result
+            # maps, a threshold change in between (new decision tables: a sequential phase) and a narrow map;
+            # the LAST call is the one compared below, the others must not disturb it
+            plan.set_pipelined(pipelined)
+            other = float(rng.choice([0.0, 0.3, 1.0]))
+            dl, dr = dev(left), dev(right)
+            nd = torch.uint8 if d <= 255 and rng.integers(0, 2) else torch.uint16
+            maps = [plan._new(pairs, torch.int32) for _ in range(2)]
+            for q in range(int(rng.integers(2, 6))):
+                plan.run(dl, dr, other if q == 1 else thr, want_best=False, web=maps[q & 1])
+            narrow, _ = plan.run(dl, dr, thr, want_best=False, web_dtype=nd)
+            web, best = plan.run(dl, dr, thr, want_best=True)
+            torch.cuda.synchronize()
+            assert torch.equal(narrow.to(torch.int32), web), (case, "narrow map of the pipelined runs", plan.describe())
+            plan.set_pipelined(0)
+        else:
+            web, best = plan.run(dev(left), dev(right), thr, want_best=True)
         el, er = plan.find_all_edges(dev(left), dev(right), thr)
-        what = (case, w, h, d, sw, mode, thr, pairs, kind, plan.describe())
+        what = (case, w, h, d, sw, mode, thr, pairs, kind, pipelined, plan.describe())
         for i in range(pairs):
             o = oracle.pipeline(imgs[i][0], imgs[i][1], thr, d, sw, mode=mode, step3=False)
             assert np.array_equal(host(el)[i], o["edges-1"]) and np.array_equal(host(er)[i], o["edges-2"]), what
@@ -1054,6 +1113,11 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["bound"] == "valu"
     assert out["roofline"]["kernel_launches_timed"] >= 6
     assert "gather_ms" in out
+    # SURVEY 8e's scaling workload rides along at N > 1: 64 x 1080p pairs, 32 per rank here, each share
+    # in one launch per step, then the 64 maps collected on rank 0 in pair order
+    c4 = out["c4"]
+    assert c4["total_pairs"] == 64 and c4["pairs_per_rank"] == 32 and c4["value"] > 0
+    assert c4["gather_ms"] > 0 and c4["maps_in_pair_order"] is True
 
 
 # ---------------------------------------------------------------------------
@@ -1080,6 +1144,107 @@ def test_narrow_web_maps_equal_the_int32_map(hip, mode, w, h, d, sw, dtype):
     assert np.array_equal(host(web32)[0], oweb), plan.describe()
     assert np.array_equal(host(webn.to(torch.int32))[0], oweb), plan.describe()
     assert torch.equal(best32, bestn)
+    plan.close()
+
+
+def test_narrow_staging_map_is_allocated_on_demand(hip):
+    """a plan of the fallback kernels does not carry the int32 staging map of the narrow
+    results until someone asks for it (sm_plan_reserve_narrow, or the first narrow request)."""
+    import ctypes as C
+    w, h, d, sw = 120, 80, 30, 23                      # popcount kernel
+    le, re = rand_edges(w, h, seed=5)
+    _, oweb = oracle.hot_path(le, re, d, sw, "toroidal")
+    plan = hip.StereoPlan(w, h, d, sw, "toroidal", max_pairs=2)
+    assert "bit-sliced" not in plan.describe()
+    base = plan.workspace_bytes()
+    plan.load_edges(dev(le), dev(re))
+    web32, _ = plan.match_wta(1, want_best=False)
+    assert plan.workspace_bytes() == base                # int32 results: nothing allocated
+    web8, _ = plan.match_wta(1, want_best=False, web_dtype=torch.uint8)
+    torch.cuda.synchronize()
+    assert plan.workspace_bytes() == base + 2 * w * h * 4
+    assert np.array_equal(host(web32)[0], oweb) and np.array_equal(host(web8.to(torch.int32))[0], oweb)
+    plan.close()
+    plan = hip.StereoPlan(w, h, d, sw, "toroidal")
+    base = plan.workspace_bytes()
+    hip.capi.check(hip.capi.lib.sm_plan_reserve_narrow(plan._h))
+    hip.capi.check(hip.capi.lib.sm_plan_reserve_narrow(plan._h))      # idempotent
+    assert plan.workspace_bytes() == base + w * h * 4
+    plan.close()
+    plan = hip.StereoPlan(300, 150, 128, 9, "toroidal")               # bit-sliced: stores narrow maps itself
+    base = plan.workspace_bytes()
+    hip.capi.check(hip.capi.lib.sm_plan_reserve_narrow(plan._h))
+    assert plan.workspace_bytes() == base
+    plan.close()
+
+
+def test_plan_options_struct_size_rules(hip):
+    """an all-zero options struct is valid (struct_size 0 = no field set); a struct LONGER
+    than this library's (a caller built against a newer header) is accepted, its known prefix taken;
+    absurd cost-mode tile heights are clamped instead of failing at launch."""
+    import ctypes as C
+    lib, vp = hip.capi.lib, C.c_void_p
+
+    class Bigger(C.Structure):
+        _fields_ = [("known", hip.capi.PlanOptions), ("future_field", C.c_int * 8)]
+
+    zero = hip.capi.PlanOptions()
+    assert zero.struct_size == 0
+    h_ = vp()
+    hip.capi.check(lib.sm_plan_create_ex(0, 300, 150, 128, 9, 0, 1, C.byref(zero), C.byref(h_)))
+    ref_desc = lib.sm_plan_describe(h_).decode()
+    lib.sm_plan_destroy(h_)
+    big = Bigger()
+    big.known.struct_size = C.sizeof(Bigger)
+    big.known.kernel_family = 1
+    for i in range(8):
+        big.future_field[i] = -1
+    h_ = vp()
+    hip.capi.check(lib.sm_plan_create_ex(0, 300, 150, 128, 9, 0, 1, C.cast(C.byref(big), C.POINTER(hip.capi.PlanOptions)),
+                                         C.byref(h_)))
+    assert "tiled kernel" in lib.sm_plan_describe(h_).decode() and "bit-sliced" in ref_desc
+    lib.sm_plan_destroy(h_)
+    neg = hip.capi.PlanOptions()
+    neg.struct_size = -4
+    h_ = vp()
+    assert lib.sm_plan_create_ex(0, 300, 150, 128, 9, 0, 1, C.byref(neg), C.byref(h_)) != 0
+    # cost-mode options out of range: clamped / ignored, results unchanged
+    left, right = make_pair(200, 50, 64, seed=3)
+    for cost in ("sad", "ssd"):
+        ob, ow = oracle.cost_hot_path(left, right, 64, 9, "toroidal", cost)
+        for opts in (dict(cost_tile_h=100000), dict(cost_pixels_per_lane=7), dict(cost_pixels_per_lane=-3, cost_tile_h=1)):
+            plan = hip.StereoPlan(200, 50, 64, 9, "toroidal", options=opts)
+            web, best = plan.cost_wta(dev(left), dev(right), cost)
+            torch.cuda.synchronize()
+            assert np.array_equal(host(web)[0], ow) and np.array_equal(host(best)[0], ob), (cost, opts)
+            plan.close()
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("w,h,d,sw,opts", [(300, 150, 128, 9, None), (1920, 64, 64, 7, None), (257, 61, 64, 7, None),
+                                          (300, 150, 128, 9, dict(edge_kernel=1)), (120, 80, 30, 23, None)])
+def test_find_edges_after_load_edges_on_one_plan(hip, mode, w, h, d, sw, opts):
+    """sm_load_edges writes EVERY column of the packed image (wrapped content included), the
+    edge kernels only the columns a valid output pixel can reach; the columns beyond keep what the load
+    left there.  No stored pixel may depend on them: load random edges, then run the gray-image pipeline
+    on the same plan and compare with the oracle -- and the other way round."""
+    left, right = make_pair(w, h, d, seed=w + h)
+    le, re = rand_edges(w, h, seed=9, density=0.6)
+    o = oracle.pipeline(left, right, 0.15, d, sw, mode=mode, step3=False)
+    ob, ow = oracle.hot_path(le, re, d, sw, mode)
+    plan = hip.StereoPlan(w, h, d, sw, mode, options=opts)
+    plan.load_edges(dev(le), dev(re))
+    web, best = plan.match_wta(1, want_best=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(web)[0], ow) and np.array_equal(host(best)[0], ob), plan.describe()
+    web, best = plan.run(dev(left), dev(right), 0.15, want_best=True)          # find_edges over the loaded image
+    torch.cuda.synchronize()
+    assert np.array_equal(host(web)[0], o["web-1"]), plan.describe()
+    assert np.array_equal(host(best)[0], o["score_best-0"]), plan.describe()
+    plan.load_edges(dev(le), dev(re))                                           # and back
+    web, best = plan.match_wta(1, want_best=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(web)[0], ow) and np.array_equal(host(best)[0], ob), plan.describe()
     plan.close()
 
 
@@ -1143,8 +1308,47 @@ def test_bench_rccl_calls_on_one_rank():
     env.update(SM_BENCH_NCCL_SELFTEST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     p = subprocess.run([sys.executable, str(root / "bench.py"), "--config", "C2", "--steps", "6",
-                        "--warmup", "2", "--gather", "--no-cpu-baseline"],
+                        "--warmup", "2", "--gather", "--no-cpu-baseline", "--c4", "--no-cost-modes", "--no-e2e"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][0]
     assert out["n_gpus"] == 1 and out["value"] > 0
+    # --c4 on one rank over the real backend: all 64 pairs in one launch, the collection a no-op
+    assert out["c4"]["pairs_per_rank"] == 64 and out["c4"]["value"] > 0 and out["c4"]["maps_in_pair_order"] is True
+
+
+def test_c_abi_rccl_collection_on_one_rank(hip):
+    """sm_comm_create / sm_broadcast / sm_gather_maps (RCCL behind the C ABI: what a C host collects its
+    maps with when they are to stay on one GPU).  All a one-GPU box can run of it: a one-rank
+    communicator -- librccl.so is loaded, ncclCommInitAll and a grouped ncclBroadcast run, the root's own
+    share of the collection is copied in rank order -- and the argument checks in front of RCCL."""
+    import ctypes as C
+    lib, check, vp = hip.capi.lib, hip.capi.check, C.c_void_p
+    comm = vp()
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.sm_comm_create(devs, 2, C.byref(comm)) == hip.capi.SM_ERR_ARG        # one rank per device
+    assert b"twice" in lib.sm_last_error()
+    assert lib.sm_comm_create((C.c_int * 1)(99), 1, C.byref(comm)) == hip.capi.SM_ERR_ARG
+    check(lib.sm_comm_create(devs, 1, C.byref(comm)))
+    assert lib.sm_comm_size(comm) == 1
+    w, h, d, sw = 320, 200, 64, 7
+    left, right = make_pair(w, h, d, seed=77)
+    plan = hip.StereoPlan(w, h, d, sw, "toroidal", max_pairs=2)
+    web, _ = plan.run(dev(np.stack([left, right])), dev(np.stack([right, left])), 0.15)
+    torch.cuda.synchronize()
+    params = torch.arange(64, dtype=torch.uint8, device="cuda")
+    bufs = (vp * 1)(params.data_ptr())
+    check(lib.sm_broadcast(comm, bufs, 64, None))
+    gathered = torch.zeros_like(web)
+    srcs = (vp * 1)(web.data_ptr())
+    sizes = (C.c_size_t * 1)(web.numel() * 4)
+    stream = (vp * 1)(torch.cuda.current_stream().cuda_stream)
+    check(lib.sm_gather_maps(comm, srcs, sizes, vp(gathered.data_ptr()), stream))
+    torch.cuda.synchronize()
+    assert torch.equal(gathered, web) and torch.equal(params.cpu(), torch.arange(64, dtype=torch.uint8))
+    o = oracle.pipeline(left, right, 0.15, d, sw, mode="toroidal", step3=False)
+    assert np.array_equal(host(gathered)[0], o["web-1"])
+    assert lib.sm_gather_maps(comm, srcs, sizes, None, None) == hip.capi.SM_ERR_ARG
+    lib.sm_comm_destroy(comm)
+    lib.sm_comm_destroy(None)
+    plan.close()
