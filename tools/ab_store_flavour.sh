@@ -1,3 +1,4 @@
+# Same-device A/B of the result-store flavours (variants sc1 / plain / nt built with -DSM_BS_STORE=1/2/0) x the two lane merges.
 export AB_ENVS="SM_LANE_MERGE=1"
 for step in "" 1; do
   export AB_STEP=$step
