@@ -92,6 +92,12 @@ def parse(argv=None):
     ap.add_argument("--c4", action="store_true",
                     help="add the `c4` object (64 x 1080p pairs sharded over the ranks + the collection of the maps "
                          "on rank 0) also at N = 1; at N > 1 it is always there")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the steps in a HIP graph (up to 100 steps per graph) and replay it: the host "
+                         "issues one launch per graph instead of two per step.  For runs under rocprofv3, whose "
+                         "per-launch overhead otherwise makes the traced process host-bound (profiles/r03: "
+                         "0.115 ms per step traced against 0.096, and the kernels themselves 13 % slower on the "
+                         "sagging clocks); the kernel time is then sampled in a short pass behind the timed region")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region, collect the maps on rank 0 over RCCL and time it")
     ap.add_argument("--no-e2e", action="store_true",
@@ -507,10 +513,35 @@ def main():
     plan.set_pipelined(args.pipeline)
     plan.prepare_threshold(args.threshold)     # set-up next to the allocations
 
-    def step():
+    def step(st=None):
         k = turn[0]
         turn[0] = k + 1 if k + 1 < resident else 0
-        check(lib.sm_run(plan._h, p_l[k], p_r[k], args.threshold, pairs, p_web[k], p_best[k], stream))
+        check(lib.sm_run(plan._h, p_l[k], p_r[k], args.threshold, pairs, p_web[k], p_best[k], st or stream))
+
+    # --graph: `gsteps` consecutive steps (a whole number of turns over the resident batches) captured once
+    graph, gsteps = None, 0
+    if args.graph:
+        gsteps = max(resident, min(args.steps, 100) // resident * resident)
+        for _ in range(2):                         # (code objects loaded, tables built: nothing lazy inside the capture)
+            step()
+        torch.cuda.synchronize(dev)
+        turn[0] = 0
+        plan.time_kernels(0)                       # launches captured into a graph cannot carry timing events
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            cs = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for _ in range(gsteps):
+                step(cs)
+        turn[0] = 0
+
+    def run_steps(n):
+        """exactly n steps: whole graphs, then single steps"""
+        if graph is not None:
+            while n >= gsteps:
+                graph.replay()
+                n -= gsteps
+        for _ in range(n):
+            step()
 
     # W warm-up steps as asked; a 4K step is ~0.1 ms, so W = 5 is over before the chip has
     # left its idle clocks (the same kernel measures ~10 % slower in the first millisecond
@@ -521,10 +552,16 @@ def main():
     # warm-up (which uses them too); re-arming them in front of the timed region is free.
     every = timing_stride(args.steps)
     n_samples = (args.steps + every - 1) // every
-    plan.time_kernels(n_samples, every)
+    if graph is None:
+        plan.time_kernels(n_samples, every)
     warm_t0 = time.perf_counter()
     warm_steps = 0
     while warm_steps < args.warmup or time.perf_counter() - warm_t0 < WARMUP_FLOOR_S:
+        if graph is not None:
+            graph.replay()
+            warm_steps += gsteps
+            torch.cuda.synchronize(dev)
+            continue
         step()
         warm_steps += 1
         if warm_steps % 16 == 0:
@@ -538,22 +575,30 @@ def main():
     # burst of untimed steps keeps it busy until the barrier + synchronize that open the timed
     # region (a timed region of 20 steps is only 2 ms long; without the burst its first
     # launches ran ~10 % slower and the line read 0.099 ms per step where 200 steps read 0.0955)
-    for _ in range(WARMUP_BURST):
-        step()
-    warm_steps += WARMUP_BURST
-    plan.time_kernels(n_samples, every)        # re-arm: same capacity, no allocation
+    burst = gsteps if graph is not None else WARMUP_BURST
+    run_steps(burst)
+    warm_steps += burst
+    if graph is None:
+        plan.time_kernels(n_samples, every)        # re-arm: same capacity, no allocation
 
     shard.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize(dev)
     shard.barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, red_dev)
 
+    if graph is not None:
+        # (hipEventRecordWithFlags(..., hipEventRecordExternal) inside the capture is refused by this runtime:
+        # the kernel time of a --graph run is sampled in a pass of single steps right behind the timed region)
+        n_samples = 16
+        plan.time_kernels(n_samples, 1)
+        for _ in range(n_samples):
+            step()
+        torch.cuda.synchronize(dev)
     kernel_ms, n_timed = plan.kernel_ms()
-    assert n_timed == n_samples
+    assert n_timed == n_samples, (n_timed, n_samples)
     units_per_step = float(w) * h * d * pairs                      # pixel-disparities / rank
     value = units_per_step * world * args.steps / elapsed / 1e6
 
@@ -611,7 +656,9 @@ def main():
         "kernel_ms_method": ("start / end time stamps of the dispatch itself (hipExtLaunchKernel events: the "
                              "clock rocprofv3's kernel trace reads), on the launch stream"
                              if "bit-sliced" in plan_text else
-                             "HIP event records around the launch, on the launch stream"),
+                             "HIP event records around the launch, on the launch stream") +
+                            (f"; --graph: sampled in a pass of {n_timed} single steps right behind the timed region "
+                             "(the timed steps themselves were replayed from a HIP graph)" if args.graph else ""),
     }
     if model:
         ach = model["wave_instructions"] / kernel_s / 1e9
@@ -661,6 +708,7 @@ def main():
             "kernel": plan_text,
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
             "pipelined": args.pipeline,
+            "graph": f"{gsteps} steps per HIP graph" if args.graph else False,
         },
         "roofline": roof,
     }

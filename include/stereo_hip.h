@@ -172,6 +172,8 @@ typedef struct sm_geometry {
     int edge_rows_per_wave;/* packed-image rows one wave of the edge kernel produces */
     int waves_per_workgroup; /* bit-sliced kernel: 1, or 2 = the upper and the lower half of a tile,
                               * sharing the window rows around the middle */
+    int lane_merge_lds;      /* bit-sliced kernel: the lanes that split a word's shift range are merged through LDS
+                              * every four rows (1) or per row with DPP (0) */
 } sm_geometry;
 int sm_plan_geometry(const sm_plan *plan, sm_geometry *out);
 /* bytes of private device workspace */

@@ -43,7 +43,7 @@ class Geometry(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "kernel", "window", "shifts_per_lane", "shift_lanes", "threads", "tile_w", "tile_h",
         "tiles_x", "tiles_y", "ext_words", "ext_rows", "pad_l", "lds_bytes", "two_wave_variant",
-        "edge_rows_per_wave", "waves_per_workgroup")]
+        "edge_rows_per_wave", "waves_per_workgroup", "lane_merge_lds")]
 
 
 class PlanOptions(C.Structure):

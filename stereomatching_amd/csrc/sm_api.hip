@@ -1003,6 +1003,7 @@ extern "C" int sm_plan_geometry(const sm_plan *plan, sm_geometry *out)
     out->two_wave_variant = g.cap2;
     out->edge_rows_per_wave = (g.w % 4 == 0) ? SM_EDGE4_ROWS : SM_EDGE_ROWS;
     out->waves_per_workgroup = plan->kernel == SM_KERNEL_BS ? (g.duo ? 2 : 1) : (g.threads + 63) / 64;
+    out->lane_merge_lds = plan->kernel == SM_KERNEL_BS && g.xmerge;
     return SM_OK;
 }
 

@@ -340,7 +340,12 @@ extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint
             const hipError_t e = hipLaunchKernel(fn, dim3(q.tiles_x, q.tiles_y, pairs), dim3(64), args,
                                                  (size_t)q.lds_bytes, (hipStream_t)stream);
             if (e != hipSuccess) return sm_fail(SM_ERR_HIP, "sm_cost_wta: %s", hipGetErrorString(e));
-            // ghost border: the columns whose windows reach left of the image, by the masked kernel
+            // Ghost border: the columns whose windows reach left of the image (x < half), by the masked kernel,
+            // BEHIND the main launch on the same stream.  (Round 4 ran this strip -- a few hundred short
+            // workgroups, 50-60 us at 4K -- BESIDE the main launch on a stream of its own, the two writing
+            // disjoint columns: the main launch then takes 130 us longer at C5 SAD, 881 vs 754 us, and 23 us at
+            // C5 SSD -- the strip's 256-thread workgroups take their CUs' LDS and wave slots first and the main
+            // launch's one-wave workgroups no longer spread evenly.  profiles/r04/ab_cost_strip_beside_rejected.txt)
             if (q.ghost && plan->square_width / 2 > 0)
                 return launch_general(plan, d_gray_left, d_gray_right, cost, pairs, d_web, d_best,
                                       plan->square_width / 2, (hipStream_t)stream);

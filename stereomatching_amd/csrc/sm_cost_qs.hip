@@ -13,7 +13,8 @@
 // the shift come for free.
 //
 // A lane owns PX pixels (4 apart) x 4*NQL shifts and keeps their window sums A as packed u16
-// (n*n*255 < 65536: windows up to 15 x 15).  Per output row and (pixel, 4 shifts):
+// (n*n*255 < 65536: windows up to 15 x 15 -- larger ones, up to the reference's default 21 x 21, keep
+// TWO packed sums per shift, see SPLIT below).  Per output row and (pixel, 4 shifts):
 //     t = E;   t = qsad(old row groups ..., t)           NG = ceil(n/4) instructions
 //     A = qsad(new row groups ..., A)                    NG
 //     A -= t                                             2 x v_pk_sub_u16
@@ -32,7 +33,14 @@
 // Ghost border: rows / columns outside the image are staged as zeros in both images, which gives
 // the oracle's "no tap outside the image, zeros past the right border" -- except for taps LEFT of
 // the image (left = 0, right(x' + d) inside).  The columns x < half are therefore recomputed
-// by the masked kernel of sm_cost.hip (launch_general with strip_cols), a launch of a few workgroups.
+// by the masked kernel of sm_cost.hip (launch_general with strip_cols), a launch of a few hundred short
+// workgroups behind this one (beside it, on a stream of its own, it costs more than it takes: sm_cost_wta).
+//
+// SPLIT (n = 17, 19, 21): a window sum reaches 21 * 21 * 255 = 112 455, more than 16 bits.  The window's
+// column groups are split between two packed accumulators -- the first three groups (12 columns: at most
+// 12 * 21 * 255 = 64 260) and the rest (at most 9 columns) -- each slid exactly as the single one; the two
+// are added as 32-bit integers only where the keys are formed (12 more full-rate instructions per pixel
+// and quad, beside 2 x NG quarter-rate v_qsad).  Keys are then sum << 8 | shift (shifts below 256).
 
 #include "sm_internal.h"
 #include "sm_cost.h"
@@ -61,8 +69,15 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
     constexpr u32 MASKR = RB == 1 ? 0x000000ffu : 0x00ffffffu;      // left bytes of the last group
     constexpr u32 MASKC = ~MASKR;                                    // 255 on the bytes zeroed there
     constexpr int WN = NG + PX - 1;                                  // right operands alive per quad
+    constexpr bool SPLIT = N * N * 255 >= 65536;                     // two packed sums per shift
+    constexpr int GL = SPLIT ? 3 : NG;                               // column groups of the first accumulator
     static_assert(RB == 1 || RB == 3, "odd windows");
-    static_assert(N * N * 255 < 65536, "window sums are packed 16-bit");
+    static_assert(4 * GL * N * 255 < 65536 && (N - 4 * GL) * N * 255 < 65536, "each packed sum must fit 16 bits");
+    static_assert(!SPLIT || NG > GL, "the split needs groups on both sides");
+    constexpr int KS = SPLIT ? 8 : 16;                               // bits of the shift in a key
+    // "nothing yet": above every real key of a chunk (a real sum is below 2^16 / 2^17) and far enough from 2^32
+    // for the chunk bases and the lane's first shift to be added without a wrap
+    constexpr u32 KNONE = SPLIT ? 0x7fffff00u : 0xffff0000u;
 
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int tid = threadIdx.x;
@@ -89,11 +104,11 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
     const int bR = bL + sl * NQL;                       // ... of shift quad 0's right operand
     const int dconst = 4 * sl * NQL - rho;              // shift of (quad 0, position 0)
 
-    u64 A[PX][NQL];
+    u64 A[PX][NQL], A2[SPLIT ? PX : 1][SPLIT ? NQL : 1];            // (A2: the second group of columns, SPLIT only)
 #pragma unroll
     for (int i = 0; i < PX; i++)
 #pragma unroll
-        for (int q = 0; q < NQL; q++) A[i][q] = 0;
+        for (int q = 0; q < NQL; q++) { A[i][q] = 0; if (SPLIT) A2[i][q] = 0; }
 
     auto ld_pair = [&](const u32 *row, int idx) -> u64 { return *reinterpret_cast<const u64a4 *>(row + idx); };
 
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
         // to the chunk (0 .. 4 CH - 1: inline constants -- with the absolute shift in the key the
         // compiler hoists a hundred scalar constants out of the row loop and spills scalar registers
         // into vector ones); the chunks' winners get their bases added at the end of the row.
-        // 0xffff0000 = "nothing yet" (a real sum is below 0xffff, and adding a base cannot wrap).
+        // KNONE = "nothing yet" (a real sum is below it, and adding a base cannot wrap).
         constexpr int CH = 16, NCH = (NQL + CH - 1) / CH;
         // (opaque copies: the 2 x NQL uniform comparisons below are otherwise computed once, outside
         // the row loop, and kept in scalar registers -- more than there are)
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
-            for (int i = 0; i < PX; i++) runc[c][i] = 0xffff0000u;
+            for (int i = 0; i < PX; i++) runc[c][i] = KNONE;
 
         // operands of quad q: right dwords bR + q + m (m < WN), E of bR + q + FG + i (i < PX).  The reads
         // of quad q + 1 are issued at the top of quad q, and nothing moves across the scheduling
@@ -183,26 +198,43 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
                 }
 #pragma unroll
                 for (int i = 0; i < PX; i++) {
-                    u64 t = ee[i];
+                    // (SPLIT: the chains of the first GL groups and of the rest run into accumulators of their
+                    // own; E belongs to the LAST group, i.e. to the second chain)
+                    u64 t = SPLIT ? 0ull : ee[i], t2 = ee[i];
                     if (!WARM) {
 #pragma unroll
-                        for (int gp = 0; gp < NG; gp++) t = qsad(ro[i + gp], gp == FG ? uop[i] : uo[i + gp], t);
-                    }
-                    u64 acc = A[i][q];
+                        for (int gp = 0; gp < GL; gp++) t = qsad(ro[i + gp], gp == FG ? uop[i] : uo[i + gp], t);
 #pragma unroll
-                    for (int gp = 0; gp < NG; gp++) acc = qsad(rn[i + gp], gp == FG ? unp[i] : un[i + gp], acc);
+                        for (int gp = GL; gp < NG; gp++) t2 = qsad(ro[i + gp], gp == FG ? uop[i] : uo[i + gp], t2);
+                    }
+                    u64 acc = A[i][q], acc2 = SPLIT ? A2[i][q] : 0ull;
+#pragma unroll
+                    for (int gp = 0; gp < GL; gp++) acc = qsad(rn[i + gp], gp == FG ? unp[i] : un[i + gp], acc);
+#pragma unroll
+                    for (int gp = GL; gp < NG; gp++) acc2 = qsad(rn[i + gp], gp == FG ? unp[i] : un[i + gp], acc2);
                     acc = pk4_sub(acc, t);
+                    if (SPLIT) acc2 = pk4_sub(acc2, t2);
                     // (pinned: nothing of a quad may sink below the quads nested in it -- the compiler
                     // otherwise reads all operands on the way in, spilling them, and computes on the way out)
                     asm volatile("" : : "v"(acc));          // (a use only: an output would cost a wait state behind it)
                     A[i][q] = acc;
+                    if (SPLIT) { asm volatile("" : : "v"(acc2)); A2[i][q] = acc2; }
                     if (OUT) {
-                        // keys: window sum << 16 | shift within the chunk; the smallest wins, i.e. the
-                        // lowest sum and among equals the FIRST shift
+                        // keys: window sum << 16 | shift within the chunk (SPLIT: << 8); the smallest wins,
+                        // i.e. the lowest sum and among equals the FIRST shift
                         constexpr int cq = 4 * (q % CH);
                         const u32 lo = (u32)acc, hi = (u32)(acc >> 32);
-                        u32 k0 = (lo << 16) | (u32)cq, k1 = bop_and_or(lo, 0xffff0000u, (u32)(cq + 1));
-                        u32 k2 = (hi << 16) | (u32)(cq + 2), k3 = bop_and_or(hi, 0xffff0000u, (u32)(cq + 3));
+                        u32 k0, k1, k2, k3;
+                        if (SPLIT) {
+                            const u32 lo2 = (u32)acc2, hi2 = (u32)(acc2 >> 32);
+                            k0 = (((lo & 0xffffu) + (lo2 & 0xffffu)) << KS) | (u32)cq;
+                            k1 = (((lo >> 16) + (lo2 >> 16)) << KS) | (u32)(cq + 1);
+                            k2 = (((hi & 0xffffu) + (hi2 & 0xffffu)) << KS) | (u32)(cq + 2);
+                            k3 = (((hi >> 16) + (hi2 >> 16)) << KS) | (u32)(cq + 3);
+                        } else {
+                            k0 = (lo << 16) | (u32)cq; k1 = bop_and_or(lo, 0xffff0000u, (u32)(cq + 1));
+                            k2 = (hi << 16) | (u32)(cq + 2); k3 = bop_and_or(hi, 0xffff0000u, (u32)(cq + 3));
+                        }
                         if (q == 0 || q >= q_tail) {        // uniform: shifts < 0 or >= D may be among these
                             const u32 dlim = (u32)g.D;
                             if ((u32)(dc + 4 * q) >= dlim) k0 = 0xffffffffu;
@@ -246,8 +278,8 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
                 const int x = x0 + 4 * i;
                 if (sl == 0 && x < g.w) {
                     const size_t o = ((size_t)pair * g.h + y) * g.w + x;
-                    web[o] = (i32)(key & 0xffffu) + 1;
-                    if (best) best[o] = (i32)(key >> 16);
+                    web[o] = (i32)(key & ((1u << KS) - 1u)) + 1;
+                    if (best) best[o] = (i32)(key >> KS);
                 }
             }
         }
@@ -280,6 +312,16 @@ static const void *sad_qs_ptr(int nql, int px)
     return nullptr;
 }
 
+// the windows with two packed sums per shift (17, 19, 21): the lane shapes their registers allow
+template <int N>
+static const void *sad_qs2_ptr(int nql, int px)
+{
+    if (nql == 17 && px == 2) return (const void *)k_sad_qs<N, 17, 2>;
+    if (nql == 9 && px == 2) return (const void *)k_sad_qs<N, 9, 2>;
+    if (nql == 5 && px == 4) return (const void *)k_sad_qs<N, 5, 4>;
+    return nullptr;
+}
+
 // fills g and returns the kernel, or nullptr if this shape is not built (caller falls back)
 const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *out)
 {
@@ -287,15 +329,17 @@ const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_le
     g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
     const int half = plan->square_width / 2, n = 2 * half + 1;
     g.ghost = plan->border == SM_GHOST;
-    if (n < 3 || n > 15 || g.D > 512 || plan->opt.cost_kernel == 1) return nullptr;     // (512: the entry's own limit)
+    if (n < 3 || n > 21 || g.D > 512 || plan->opt.cost_kernel == 1) return nullptr;     // (512: the entry's own limit)
+    const bool split = n > 15;                      // two packed sums per shift: 8 key bits for the shift
+    if (split && g.D > 240) return nullptr;
     const int nq = (g.D + 3 + 3) / 4;               // quads that cover shifts -3 .. D-1
     int nql, px;
     if (nq <= 5) { nql = 5; px = 4; }
-    else if (nq <= 9) { nql = 9; px = 4; }
-    else if (nq <= 17) { nql = 17; px = 4; }
+    else if (nq <= 9) { nql = 9; px = split ? 2 : 4; }
+    else if (nq <= 17 || split) { nql = 17; px = split ? 2 : 4; }
     else { nql = 33; px = 2; }
     // (an explicit choice applies where both widths are built; anything else is ignored, not launched)
-    if ((plan->opt.cost_pixels_per_lane == 2 || plan->opt.cost_pixels_per_lane == 4) && nql == 17) px = plan->opt.cost_pixels_per_lane;
+    if ((plan->opt.cost_pixels_per_lane == 2 || plan->opt.cost_pixels_per_lane == 4) && nql == 17 && !split) px = plan->opt.cost_pixels_per_lane;
     g.nl = 1; g.log2nl = 0;
     while (g.nl * nql < nq) { g.nl <<= 1; g.log2nl++; }
     g.tw = 4 * px * (16 / g.nl);
@@ -344,6 +388,9 @@ const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_le
     case 11: fn = sad_qs_ptr<11>(nql, px); break;
     case 13: fn = sad_qs_ptr<13>(nql, px); break;
     case 15: fn = sad_qs_ptr<15>(nql, px); break;
+    case 17: fn = sad_qs2_ptr<17>(nql, px); break;
+    case 19: fn = sad_qs2_ptr<19>(nql, px); break;
+    case 21: fn = sad_qs2_ptr<21>(nql, px); break;
     }
     *out = g;
     return fn;

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
     const int lw = g.lrow >> 2, rw = g.rrow >> 2;                    // dwords per staged row
     u32 *sL = lds;                                                   // [nsr][lw]
     u32 *sR = sL + g.nsr * lw;                                       // [nsr][rw]
-    // RR of the current output row by right byte position (the window centre), flat.  The lanes of a wave
+    // -(RR << 8) of the current output row by right byte position (the window centre), flat: negated and shifted
+    // once per position where it is updated, not 44 times per lane and row where it is read.  The lanes of a wave
     // that differ in their shift-lane read entries 32 apart -- the same bank: 8-way conflicts on the 44
     // reads of a lane and row at 256 shifts.  An interleaved [position][shift-lane] table removes them
     // (178 M -> 21 M conflict cycles at C5) and was measured SLOWER, 1.32 vs 1.22 ms: keeping it
@@ -98,32 +99,25 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
         const u32 *rowLo = sL + ro_i * lw, *rowRo = sR + ro_i * rw;
 
         // RR: per right byte position q (the window centre), + the new row's horizontal sum of squares
-        // - the old row's; a lane takes four consecutive positions a turn (their windows are the four
-        // byte alignments of the same dwords).  Positions whose window leaves the staged row are never read.
+        // - the old row's.  Positions whose window leaves the staged row are never read.
 #ifndef SSD_EXPERIMENT_NO_RR     // (timing experiment only: how much of a row is the RR update)
-        for (int k = tid; k <= rw - NG - 2; k += 64) {
-            u32 rn_[NG + 2], ro_[NG + 2];
+        // (one position per lane and turn: 4 x 76 positions are 4.75 turns of 64 lanes; four positions per lane
+        // -- the four alignments of the same dwords -- were 2 turns of which the second had 12 lanes at work)
+        for (int it = tid; it < 4 * (rw - NG - 1); it += 64) {
+            const int k = it >> 2, i = it & 3;          // position q = 4 k + HALF + i: its window starts at byte 4 k + i
+            u32 sn = 0, so = 0;
 #pragma unroll
-            for (int c = 0; c < NG + 2; c++) {
-                rn_[c] = rowRn[k + c];
-                if (!WARM) ro_[c] = rowRo[k + c];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {               // position q = 4 k + HALF + i: its window starts at byte 4 k + i
-                u32 sn = 0, so = 0;
-#pragma unroll
-                for (int gp = 0; gp < NG; gp++) {
-                    u32 v = i ? __builtin_amdgcn_alignbyte(rn_[gp + 1], rn_[gp], i) : rn_[gp];
-                    if (gp == FG) v &= MASKR;
-                    sn = dot4(v, v, sn);
-                    if (!WARM) {
-                        u32 u = i ? __builtin_amdgcn_alignbyte(ro_[gp + 1], ro_[gp], i) : ro_[gp];
-                        if (gp == FG) u &= MASKR;
-                        so = dot4(u, u, so);
-                    }
+            for (int gp = 0; gp < NG; gp++) {
+                u32 v = __builtin_amdgcn_alignbyte(rowRn[k + gp + 1], rowRn[k + gp], i);
+                if (gp == FG) v &= MASKR;
+                sn = dot4(v, v, sn);
+                if (!WARM) {
+                    u32 u = __builtin_amdgcn_alignbyte(rowRo[k + gp + 1], rowRo[k + gp], i);
+                    if (gp == FG) u &= MASKR;
+                    so = dot4(u, u, so);
                 }
-                sRR[4 * k + HALF + i] += sn - so;
             }
+            sRR[4 * k + HALF + i] -= (sn - so) << 8;       // the table holds -(RR << 8): what the keys take
         }
         __syncthreads();
 #endif
@@ -148,6 +142,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
             }
         }
         // LL of the lane's pixels (only `best` needs it: the arg-min does not depend on it)
+        if (best) {             // uniform
 #pragma unroll
         for (int p = 0; p < PX; p++) {
             u32 sn = 0, so = 0;
@@ -158,6 +153,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                 if (!WARM) { const u32 u = gp == FG ? uop[p] : uo[p + gp]; so = dot4(u, u, so); }
             }
             LLs[p] += sn - so;
+        }
         }
 
         i32 run[PX];
@@ -196,12 +192,12 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
             u32 nrr[PX + 1];            // -(RR << 8) of the window's entries
             if (OUT) {
 #pragma unroll
-                for (int p = 0; p < PX; p++) nrr[p] = 0u - (sRR[r0 + 4 * p + i] << 8);
+                for (int p = 0; p < PX; p++) nrr[p] = sRR[r0 + 4 * p + i];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < NQ; m++) {
-                if (OUT && m + 1 < NQ) nrr[PX] = 0u - (sRR[r0 + 4 * (PX + m) + i] << 8);
+                if (OUT && m + 1 < NQ) nrr[PX] = sRR[r0 + 4 * (PX + m) + i];
                 // the PX pixels' chains side by side, group by group: a v_dot4 that accumulates onto the one
                 // issued just before it costs a wait state (three before any other reader), and the compiler
                 // pads with s_nop what the source order does not separate

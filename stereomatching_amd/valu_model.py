@@ -30,8 +30,10 @@ def variant_key(geom: dict, num_shifts: int, border: int, want_best: bool) -> st
     duo = ":duo" if geom["kernel"] == 4 and geom.get("waves_per_workgroup", 1) == 2 else ""
     # the build capped at two waves per SIMD is code of its own (the register cap can move spills)
     cap2 = ":cap2" if geom["kernel"] == 4 and geom.get("two_wave_variant") else ""
+    # the lanes of a word merged through LDS every four rows: other code in the row loop
+    xm = ":xm" if geom["kernel"] == 4 and geom.get("lane_merge_lds") else ""
     return (f"k{geom['kernel']}:n{geom['window']}:ds{geom['shifts_per_lane']}:nl{geom['shift_lanes']}:"
-            f"{'ghost' if border else 'toroidal'}:fulld{int(fulld)}:best{int(bool(want_best))}{duo}{cap2}")
+            f"{'ghost' if border else 'toroidal'}:fulld{int(fulld)}:best{int(bool(want_best))}{duo}{cap2}{xm}")
 
 
 def waves_and_rows(geom: dict, height: int, pairs: int):

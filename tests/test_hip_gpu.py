@@ -771,6 +771,13 @@ SAD_QS = [  # (w, h, D, S): quads per lane / shift-lanes / pixels per lane of th
     (72, 45, 140, 15),      # 2 shift-lanes, the lower one full, the upper one mostly empty; 15x15
     (40, 30, 17, 5),        # D = 4 k + 1
     (16, 12, 3, 3),         # tiny
+    # windows above 15 x 15 (SAD: two packed sums per shift; SSD takes the general kernel there)
+    (96, 44, 30, 21),       # the reference's defaults: 21 x 21, 30 shifts -> 9 quads x 2 pixels
+    (61, 40, 12, 17),       # 5 quads x 4 pixels, width not a multiple of 4
+    (140, 43, 64, 19),      # 17 quads x 2 pixels
+    (120, 45, 200, 21),     # 4 shift-lanes of 17 quads, the last one all beyond D in its second chunk
+    (88, 47, 240, 17),      # the most shifts the 8-bit shift field of the split keys is used for
+    (90, 46, 250, 21),      # ... beyond it: the general kernel
 ]
 
 
@@ -779,8 +786,8 @@ SAD_QS = [  # (w, h, D, S): quads per lane / shift-lanes / pixels per lane of th
 @pytest.mark.parametrize("cost", ["sad", "ssd"])
 @pytest.mark.parametrize("w,h,d,sw", SAD_QS)
 def test_quad_sad_kernel_matches_own_oracle(hip, mode, tile_h, cost, w, h, d, sw):
-    """k_sad_qs / k_ssd_dot: every shape of (quads per lane, shift-lanes), windows 3 .. 15 (SSD: .. 11, the
-    larger ones take the general kernel), both borders, tiles of 3 rows (several slides per wave, a
+    """k_sad_qs / k_ssd_dot: every shape of (quads per lane, shift-lanes), windows 3 .. 21 (SAD from 17 on with
+    two packed sums per shift; SSD: .. 11, the larger ones take the general kernel), both borders, tiles of 3 rows (several slides per wave, a
     ragged last tile) and the plan's own height, unaligned input"""
     left, right = make_pair(w, h, d, seed=w * 3 + d, kind="noise" if (w + d) % 3 == 0 else "scene")
     if (w + h) % 2:             # saturate some pixels: 0 and 255 are the masked-SAD corner cases
@@ -795,6 +802,25 @@ def test_quad_sad_kernel_matches_own_oracle(hip, mode, tile_h, cost, w, h, d, sw
     web2, best2 = gen.cost_wta(dev(left), dev(right), cost)
     assert torch.equal(web2, web) and torch.equal(best2, best)
     plan.close(); gen.close()
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("sw", [15, 17, 19, 21])
+def test_quad_sad_largest_possible_sums(hip, mode, sw):
+    """black against white: every tap costs 255, the window sums are the largest the packed 16-bit
+    accumulators ever see (15 x 15: 57 375 in one; 21 x 21: 64 260 + 48 195 in two), every shift ties
+    (the first must win), and a lone matching column must still be found"""
+    w, h, d = 100, sw + 7, 40
+    left = np.zeros((h, w), np.uint8)
+    right = np.full((h, w), 255, np.uint8)
+    right[:, 60] = 0                       # one column of zero cost: windows that hold it prefer its shift
+    plan = hip.StereoPlan(w, h, d, sw, mode)
+    web, best = plan.cost_wta(dev(left), dev(right), "sad")
+    ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, "sad")
+    assert np.array_equal(host(web)[0], ow) and np.array_equal(host(best)[0], ob)
+    if mode == "toroidal":
+        assert int(ob.max()) == sw * sw * 255
+    plan.close()
 
 
 @pytest.mark.parametrize("cost", ["sad", "ssd"])
@@ -828,7 +854,7 @@ def test_cost_kernels_random_shapes_match_own_oracle(hip):
     soak = int(os.environ.get("SM_SOAK_COST", "0"))
     rng = np.random.default_rng(int(os.environ.get("SM_SOAK_SEED", "1")) + 977 if soak else 20261004)
     for case in range(soak or 160):
-        sw = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 4, 8]))
+        sw = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 4, 8, 19, 21, 20]))
         w = int(rng.integers(max(8, sw), 701 if soak else 301))
         if case % 3 == 0:
             w = 4 * ((w + 3) // 4)

@@ -39,9 +39,12 @@ for f in newest(str(src / "kt" / "*" / "*_kernel_trace.csv")):
             g = max(gs for gs, _ in v)
             ds = [d for gs, d in v if gs == g]           # full-size dispatches only
             out.write(f'"{name}",{len(ds)},{sum(ds)},{sum(ds) / len(ds):.1f},{100 * sum(ds) / tot:.2f},{min(ds)},{max(ds)},{g}\n')
-bench = [l for l in (src / "bench.json").read_text().splitlines() if l.startswith("{")]
-if bench:
-    (dst / "bench.json").write_text(bench[-1] + "\n")
+for name in ("bench", "bench_driver_flags", "bench_graph", "bench_traced", "bench_after"):
+    f = src / f"{name}.json"
+    if f.exists():
+        bench = [l for l in f.read_text().splitlines() if l.startswith("{")]
+        if bench:
+            (dst / f"{name}.json").write_text(bench[-1] + "\n")
 
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob(str(src / "pmc_*"))):
