@@ -92,12 +92,17 @@ def parse(argv=None):
     ap.add_argument("--c4", action="store_true",
                     help="add the `c4` object (64 x 1080p pairs sharded over the ranks + the collection of the maps "
                          "on rank 0) also at N = 1; at N > 1 it is always there")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the steps in a HIP graph (up to 100 steps per graph) and replay it: the host "
-                         "issues one launch per graph instead of two per step.  For runs under rocprofv3, whose "
-                         "per-launch overhead otherwise makes the traced process host-bound (profiles/r03: "
-                         "0.115 ms per step traced against 0.096, and the kernels themselves 13 % slower on the "
-                         "sagging clocks); the kernel time is then sampled in a short pass behind the timed region")
+    ap.add_argument("--graph", action="store_true", default=True,
+                    help="(default) capture the steps in a HIP graph (up to 100 steps per graph) and replay it: the "
+                         "host issues one launch per graph instead of two per step, the kernels of the timed region "
+                         "run back to back from its first microsecond (a 20-step region is 2 ms: launched step by step "
+                         "its first kernels run on clocks that sagged during the barrier in front of it, -7 %%), and a "
+                         "run under rocprofv3 stays GPU-bound (profiles/r03: traced 0.115 ms per step against 0.096).  "
+                         "Launches inside a captured graph cannot carry timing events: the kernel time is sampled in 16 "
+                         "single steps right behind the timed region")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="launch every step from the host; the match launches of the timed region then carry their "
+                         "own timing events (every 8th, every 2nd at --steps 20)")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region, collect the maps on rank 0 over RCCL and time it")
     ap.add_argument("--no-e2e", action="store_true",
@@ -519,19 +524,24 @@ def main():
         check(lib.sm_run(plan._h, p_l[k], p_r[k], args.threshold, pairs, p_web[k], p_best[k], st or stream))
 
     # --graph: `gsteps` consecutive steps (a whole number of turns over the resident batches) captured once
-    graph, gsteps = None, 0
-    if args.graph:
-        gsteps = max(resident, min(args.steps, 100) // resident * resident)
-        for _ in range(2):                         # (code objects loaded, tables built: nothing lazy inside the capture)
-            step()
-        torch.cuda.synchronize(dev)
-        turn[0] = 0
-        plan.time_kernels(0)                       # launches captured into a graph cannot carry timing events
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            cs = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            for _ in range(gsteps):
-                step(cs)
+    graph, gsteps, graph_note = None, 0, None
+    if args.graph and not args.pipeline and args.steps >= resident:
+        try:
+            gsteps = max(resident, min(args.steps, 100) // resident * resident)
+            for _ in range(2):                     # (code objects loaded, tables built: nothing lazy inside the capture)
+                step()
+            torch.cuda.synchronize(dev)
+            turn[0] = 0
+            plan.time_kernels(0)                   # launches captured into a graph cannot carry timing events
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                cs = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for _ in range(gsteps):
+                    step(cs)
+        except Exception as exc:      # noqa: BLE001 -- never fatal: the steps are then launched one by one
+            graph, gsteps = None, 0
+            graph_note = f"capture failed ({type(exc).__name__}): steps launched from the host"
+            torch.cuda.synchronize(dev)
         turn[0] = 0
 
     def run_steps(n):
@@ -658,7 +668,7 @@ def main():
                              if "bit-sliced" in plan_text else
                              "HIP event records around the launch, on the launch stream") +
                             (f"; --graph: sampled in a pass of {n_timed} single steps right behind the timed region "
-                             "(the timed steps themselves were replayed from a HIP graph)" if args.graph else ""),
+                             "(the timed steps themselves were replayed from a HIP graph)" if graph is not None else ""),
     }
     if model:
         ach = model["wave_instructions"] / kernel_s / 1e9
@@ -708,7 +718,7 @@ def main():
             "kernel": plan_text,
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
             "pipelined": args.pipeline,
-            "graph": f"{gsteps} steps per HIP graph" if args.graph else False,
+            "graph": f"{gsteps} steps per HIP graph" if graph is not None else (graph_note or False),
         },
         "roofline": roof,
     }

@@ -1005,7 +1005,10 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
         // pixel pfirst of the word, in chunks of up to 4.  nib = the chunk's bits of a plane;
         // nib * 0x204081 puts copy j of the nibble at bit 7j, so bit 8q holds pixel q's bit:
         // & 0x01010101 leaves one byte per pixel, and byte lanes then add up the planes.
-        auto emit_pixels = [&](u32 (&B)[SB], u32 (&arg)[ABMAX], int xw, int yy, int pfirst, int per) {
+        // (pstep: pixels between a lane's consecutive chunks -- 4 where a lane owns a run of `per` pixels; the lanes
+        // that share an item of the LDS merge interleave their chunks, so that one store instruction writes
+        // 16 * lanes-per-item contiguous bytes of every word)
+        auto emit_pixels = [&](u32 (&B)[SB], u32 (&arg)[ABMAX], int xw, int yy, int pfirst, int per, int pstep) {
             const int cw = per < 4 ? per : 4;          // pixels per chunk
             const u32 cmask = (1u << cw) - 1u;
             u32 allone = B[0];
@@ -1023,8 +1026,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
                 arg[k] = bop<BOP_SEL>(allone, (u32)-(i32)((dm1 >> k) & 1u), arg[k]);
             }
 #endif
-            for (int c = 0; c < per; c += 4) {
-                const int p0 = pfirst + c;
+            for (int c = 0, p0 = pfirst; c < per; c += 4, p0 += pstep) {
                 u32 bb = 0, bhi = 0, alo = 0, ahi = 0;
                 if (best) {                          // uniform: the counts are wanted at all
 #pragma unroll
@@ -1214,14 +1216,16 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
                 }
                 const int tt = t - r + rr;                      // the item's output row of this wave
                 const int yy = y0 + sgn * tt;
-                // (Each lane stores 16-byte pieces of its own pixels, 64 bytes apart at nl = 8: routing the
-                // integers through LDS so that every store instruction writes whole rows was built and measured --
-                // no better at C3 / C5 (90.6 vs 89.5 us), the extra LDS round trip costs what the contiguous
-                // stores gain; the store flavour matters far more: with `nt` instead of `sc1` such pieces cost a
-                // factor 2.3 at 8 x 1080p.  profiles/r04/ab_store_flavour.txt, ab_lane_merge*.txt)
+                // (The lanes of an item interleave their 4-pixel chunks: one store instruction writes 16 * lpi
+                // contiguous bytes of every word -- with a RUN of pixels per lane the 16-byte pieces lay 64 bytes
+                // apart and the write-through stores moved every 32-byte sector twice: WRITE_SIZE 64 800 KiB per C3
+                // launch for a 32 400 KiB map.  Routing the integers through LDS so that every store writes whole
+                // rows was built and measured -- no better at C3 / C5 (90.6 vs 89.5 us), the extra LDS round trip
+                // costs what the contiguous stores gain; the store flavour matters far more: with `nt` instead of
+                // `sc1` scattered pieces cost a factor 2.3 at 8 x 1080p.  profiles/r04/ab_store_flavour.txt)
                 if (rr <= r && yy < g.h && yy >= 0) {
                     const int per = 32 >> l2lpi;
-                    emit_pixels(Bm, am, tx0 + 32 * wr, yy, sub * per, per);
+                    emit_pixels(Bm, am, tx0 + 32 * wr, yy, 4 * sub, per, 4 * lpi);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1239,7 +1243,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
             // pixels [s * per, s * per + per), per = 32 / nl
             if (y < g.h) {
                 const int per = 32 >> g.log2nl;            // nl <= 32
-                emit_pixels(B, arg, x0, y, s * per, per);
+                emit_pixels(B, arg, x0, y, s * per, per, 4);
             }
         }
 #undef SM_MERGE

@@ -6,7 +6,7 @@
 # Kernel trace and PMC passes are separate runs (never combined with other trace domains), as the pool
 # requires.  Order: unprofiled runs first (same box, same clocks), then the trace, then the counters.
 #
-# The TRACED run replays its steps from a HIP graph (bench.py --graph, 2000 steps): under the tracer a
+# bench.py replays its steps from a HIP graph (its default; 2000 steps in the traced run): under the tracer a
 # launch costs the host more than the 0.09 ms a step takes, the traced process of round 3 was host-bound
 # (0.115 ms per step) and its kernels ran 13 % slower on the sagging clocks than the bench line next to
 # them.  Replayed from a graph the traced process is GPU-bound like the untraced one, and the trace's
@@ -20,8 +20,10 @@ rm -rf "$OUT"   # gpurun merges results into the build box's copy: delete that o
 mkdir -p "$OUT"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || echo "bench failed"
 python3 bench.py --steps 20 --warmup 5 $F > "$OUT/bench_driver_flags.json" 2> "$OUT/bench_driver_flags.err" || echo "bench (driver flags) failed"
-python3 bench.py --steps 2000 --graph $F > "$OUT/bench_graph.json" 2> "$OUT/bench_graph.err" || echo "bench --graph failed"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --steps 2000 --graph $F > "$OUT/bench_traced.json" 2> "$OUT/kt.log" || echo "kernel-trace run failed"
+python3 bench.py --no-graph $F > "$OUT/bench_nograph.json" 2> "$OUT/bench_nograph.err" || echo "bench --no-graph failed"
+python3 bench.py --no-graph --steps 20 --warmup 5 $F > "$OUT/bench_nograph_driver_flags.json" 2> "$OUT/bench_nograph_driver_flags.err" || echo "bench --no-graph (driver flags) failed"
+python3 bench.py --steps 2000 $F > "$OUT/bench_graph.json" 2> "$OUT/bench_graph.err" || echo "bench --steps 2000 failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --steps 2000 $F > "$OUT/bench_traced.json" 2> "$OUT/kt.log" || echo "kernel-trace run failed"
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do

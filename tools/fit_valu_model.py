@@ -22,7 +22,11 @@ points = collections.defaultdict(list)
 for meta_file in sorted(src.glob("*/meta.json")):
     meta = json.loads(meta_file.read_text())
     vals, waves = [], []
-    for f in glob.glob(str(meta_file.parent / "prof" / "*" / "*_counter_collection.csv")):
+    # (gpurun MERGES a call's output into the local gpurun_out/: files of an earlier round's passes may
+    # lie next to this one's -- only the newest counter file of a case counts)
+    files = sorted(glob.glob(str(meta_file.parent / "prof" / "*" / "*_counter_collection.csv")),
+                   key=lambda f: Path(f).stat().st_mtime)
+    for f in files[-1:]:
         rows = [r for r in csv.DictReader(open(f)) if "k_match" in r["Kernel_Name"]]
         full = max((int(r["Grid_Size"]) for r in rows), default=0)
         for r in rows:
@@ -57,6 +61,12 @@ for key, pts in points.items():
 prof.parent.mkdir(parents=True, exist_ok=True)
 prof.write_text(json.dumps({"points": points}, indent=1, sort_keys=True) + "\n")
 out = ROOT / "stereomatching_amd" / "valu_counts.json"
-out.write_text(json.dumps({"source": f"SQ_INSTS_VALU of rocprofv3 --pmc passes ({prof})",
-                           "variants": variants}, indent=1, sort_keys=True) + "\n")
+# variants this set of passes did not touch keep their earlier fit (each entry says where it was fitted)
+merged = json.loads(out.read_text()).get("variants", {}) if out.exists() else {}
+for v in variants.values():
+    v["fitted_in"] = str(prof)
+merged.update(variants)
+out.write_text(json.dumps({"source": f"SQ_INSTS_VALU of rocprofv3 --pmc passes ({prof}; variants these passes did not "
+                                     "touch keep their earlier fit, see fitted_in)",
+                           "variants": merged}, indent=1, sort_keys=True) + "\n")
 print("wrote", prof, "and", out)

@@ -32,10 +32,12 @@ out = [f"Results of round {tag[1:].lstrip('0')}, one MI355X, resident inputs. So
        f"(one `tools/collect_profiles.sh {tag}` call = one box; boxes of the pool differ by up to ≈ 10 % in absolute time)."]
 
 # ---- bench lines of the collection call
-rows = [("default run (`bench.json`: 200 steps)", "bench.json"),
+rows = [("default run (`bench.json`: 200 steps, replayed from HIP graphs)", "bench.json"),
         ("the driver's flags (`bench_driver_flags.json`: `--steps 20 --warmup 5`)", "bench_driver_flags.json"),
-        ("`--graph --steps 2000`, untraced (`bench_graph.json`)", "bench_graph.json"),
-        ("`--graph --steps 2000` UNDER `rocprofv3 --kernel-trace` (`bench_traced.json`)", "bench_traced.json"),
+        ("`--no-graph`, 200 steps launched from the host (`bench_nograph.json`)", "bench_nograph.json"),
+        ("`--no-graph --steps 20 --warmup 5` (`bench_nograph_driver_flags.json`)", "bench_nograph_driver_flags.json"),
+        ("`--steps 2000`, untraced (`bench_graph.json`)", "bench_graph.json"),
+        ("`--steps 2000` UNDER `rocprofv3 --kernel-trace` (`bench_traced.json`)", "bench_traced.json"),
         ("default flags again, after the PMC passes (`bench_after.json`)", "bench_after.json")]
 tab = ["| `bench.py` run, C3 (4K pair, 128 shifts, 9×9, toroidal) | value (M Mpx-disp/s) | ms per step | `roofline.kernel_ms` | VALU instr / launch | `frac` | of sustained |",
        "|---|---|---|---|---|---|---|"]
@@ -55,7 +57,7 @@ if len(tab) > 2:
 ks = P / "kernel_stats.csv"
 if ks.exists():
     krows = list(csv.DictReader(open(ks)))
-    t2 = ["| kernel (trace of the `--graph` run, full-size dispatches) | calls | average µs | min µs | max µs | share |", "|---|---|---|---|---|---|"]
+    t2 = ["| kernel (trace of the 2000-step run, full-size dispatches) | calls | average µs | min µs | max µs | share |", "|---|---|---|---|---|---|"]
     match_avg = None
     for r in krows:
         name = r["Name"].split("(")[0].replace("void ", "")
@@ -134,7 +136,9 @@ if d:
     if "e2e" in d and isinstance(d["e2e"], dict) and "error" not in d["e2e"]:
         e = d["e2e"]
         ex.append("`e2e` (PCIe-inclusive, never `value`): " + ", ".join(f"{k} {v}" for k, v in e.items()
-                                                                          if isinstance(v, (int, float)) and "ms" in k))
+                                                                          if isinstance(v, (int, float)) and "ms" in k) +
+                  ", ".join(f"{k} map {v['ms_per_pair']} ms per 4K pair ({v['pcie_GBps']} GB/s over PCIe)" for k, v in e.items()
+                            if isinstance(v, dict) and "ms_per_pair" in v))
     if ex:
         out += ["", "Extras of the default line: " + "; ".join(ex) + "."]
 

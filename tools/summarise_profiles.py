@@ -39,7 +39,7 @@ for f in newest(str(src / "kt" / "*" / "*_kernel_trace.csv")):
             g = max(gs for gs, _ in v)
             ds = [d for gs, d in v if gs == g]           # full-size dispatches only
             out.write(f'"{name}",{len(ds)},{sum(ds)},{sum(ds) / len(ds):.1f},{100 * sum(ds) / tot:.2f},{min(ds)},{max(ds)},{g}\n')
-for name in ("bench", "bench_driver_flags", "bench_graph", "bench_traced", "bench_after"):
+for name in ("bench", "bench_driver_flags", "bench_nograph", "bench_nograph_driver_flags", "bench_graph", "bench_traced", "bench_after"):
     f = src / f"{name}.json"
     if f.exists():
         bench = [l for l in f.read_text().splitlines() if l.startswith("{")]
