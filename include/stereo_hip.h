@@ -131,7 +131,7 @@ typedef struct sm_plan_options {
                                  * 0 is read as "no field set" (so `sm_plan_options o = {0}` is valid) */
     int kernel_family;          /* 1 = the popcount kernels (general fallback) even where the bit-sliced one is built */
     int tile_h;                 /* match kernel: output rows per wave */
-    int shifts_per_lane;        /* bit-sliced kernel: 8 or 16 */
+    int shifts_per_lane;        /* bit-sliced kernel: 4, 8 or 16 */
     int workgroup_waves;        /* bit-sliced kernel: 1 = one-wave workgroups, 2 = two-wave workgroups (shared warm-up) */
     int no_two_wave_cap;        /* 1 = never launch the variant capped at two waves per SIMD */
     unsigned priority_pattern;  /* bit-sliced kernel: time-sliced wave priority, bit k = favoured slot parity in unit k */
@@ -149,6 +149,8 @@ typedef struct sm_plan_options {
     int lane_merge;             /* bit-sliced kernel: how the lanes that split a word's shift range are merged:
                                  * 1 = per row with DPP, 2 = through LDS every four rows (where >= 4 lanes share a word);
                                  * 0 = the plan's choice */
+    int no_four_shift_lanes;    /* bit-sliced kernel: 1 = never 4 shifts per lane (the plan's own choice is between 16, 8
+                                 * and 4); shifts_per_lane = 4 forces them where they are built */
 } sm_plan_options;
 int sm_plan_create_ex(int device, int width, int height, int num_shifts, int square_width,
                       int border, int max_pairs, const sm_plan_options *options, sm_plan **out);

@@ -52,7 +52,8 @@ class PlanOptions(C.Structure):
                 ("shifts_per_lane", C.c_int), ("workgroup_waves", C.c_int), ("no_two_wave_cap", C.c_int),
                 ("priority_pattern", C.c_uint), ("edge_kernel", C.c_int), ("timing_by_records", C.c_int),
                 ("cost_pixels_per_lane", C.c_int), ("cost_tile_h", C.c_int), ("cost_kernel", C.c_int),
-                ("priority_class", C.c_int), ("priority_on_change", C.c_int), ("lane_merge", C.c_int)]
+                ("priority_class", C.c_int), ("priority_on_change", C.c_int), ("lane_merge", C.c_int),
+                ("no_four_shift_lanes", C.c_int)]
 
     @classmethod
     def make(cls, **kw):

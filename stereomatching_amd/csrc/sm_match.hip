@@ -565,7 +565,7 @@ int sm_match_configure(sm_plan *plan)
         const double warm = duo ? 0.42 * (o.half + 1) + 2.3
                           : bs ? 0.42 * (o.n - 1) + 1.8 : 0.4 * (o.n - 1) + 1.0;
         // lane-row work relative to ds = 16: the per-row shared views and one more merge level
-        const double work = ds == 16 ? 1.0 : 0.5 * 1.10;
+
         // duo: 2 * th rows per workgroup, and behind the staged rows the exchange block
         // [2 halves of the shifts][ds / 2 * SB / 2 plane pairs][64 lanes] of 8 bytes
         int sb = 0;
@@ -573,7 +573,7 @@ int sm_match_configure(sm_plan *plan)
         const int rows_per_wg = duo ? 2 : 1;
         // lane merge through LDS (k_match_bs, g.xmerge): where at least 4 lanes share a word; per wave
         // 4 x NPG blocks of 1 KB behind the staged rows, in a two-wave workgroup over the exchange slots
-        const int ab = ds == 16 ? 4 : 3;
+        const int ab = ds == 16 ? 4 : ds == 8 ? 3 : 2;
         const int npg = (sb + ab + 3) / 4;
         // Taken where it pays: 16 shifts per lane and at least 8 lanes per word (C3: -4.3 % of the launch's
         // VALU instructions, -3 % of its time; C5: -10 %).  With 4 lanes per word there are only two DPP levels
@@ -582,7 +582,11 @@ int sm_match_configure(sm_plan *plan)
         // it is possible (tests, measurements), 1 forbids it.  profiles/r04/ab_lane_merge.txt
         const bool xm_possible = bs && o.log2nl >= 2 && o.nl <= 32;
         o.xmerge = xm_possible && plan->opt.lane_merge != 1 &&
-                   (plan->opt.lane_merge == 2 || (ds == 16 && o.log2nl >= 3));
+                   (plan->opt.lane_merge == 2 || ((ds == 16 || ds == 4) && o.log2nl >= 3));
+        // lane-row work relative to ds = 16: the per-row shared views and the merge levels weigh more the fewer
+        // shifts a lane carries (fitted to same-device timings: profiles/r02/ds8_small_grids_sweep.txt, r04/ab_ds4.txt)
+        const double work = ds == 16 ? 1.0 : ds == 8 ? 0.5 * 1.10
+                          : o.xmerge ? 0.25 * 1.43 : 0.25 * (1.30 + 0.15 * o.log2nl);
         const int mb_words = o.xmerge ? npg * 1024 : 0;
         auto lds_words = [&](int th, int &xm_off) {
             const int staged = ((rows_per_wg * th + o.n - 1) * rows_words + 3) & ~3;
@@ -700,19 +704,30 @@ int sm_match_configure(sm_plan *plan)
         ds = sm_bs_default_ds(g.n);
         int l2;
         const bool has8 = sm_bs_kernel_ptr(g.n, 8, true, ghost, false) && nl_for(8, l2) <= 32;
-        if ((ds_env == 8 || ds_env == 16) && sm_bs_kernel_ptr(g.n, ds_env, true, ghost, false) &&
+        if ((ds_env == 4 || ds_env == 8 || ds_env == 16) && sm_bs_kernel_ptr(g.n, ds_env, true, ghost, false) &&
             nl_for(ds_env, l2) <= 32) {
             ds = ds_env;
-        } else if (ds == 16 && has8) {
-            // A grid that leaves most SIMDs with ONE wave (a single 1080p pair: 864 workgroups)
-            // runs at the rate of a lone wave; with 8 shifts per lane the same job is twice the
-            // workgroups of roughly half the work each, i.e. two waves per SIMD.  The cost model
-            // decides (measured: C2 29.6 -> 23.4 us, C1 18.4 -> 12.0 us; the full-chip
-            // configurations stay at 16).
-            MatchGeom g16, g8;
-            int r16 = 0, r8 = 0;
-            const double c16 = configure_best(16, g16, r16), c8 = configure_best(8, g8, r8);
-            if (c8 < 0.95 * c16) ds = 8;
+        } else {
+            // A grid that leaves most SIMDs with ONE wave (a single 1080p pair at 16 shifts per lane: 864
+            // workgroups) runs at the rate of a lone wave; with 8 -- or 4 -- shifts per lane the same job is
+            // more workgroups of less work each, on narrower tiles that can be taller for the same number of
+            // waves (less warm-up per output row).  The cost model decides, with 5 % in favour of the wider
+            // lane.  Measured: C2 29.6 (16) -> 19.1 (8) -> 16.5 us (4, lanes merged through LDS), C1 18.4 ->
+            // 9.8 -> 7.2 us; the full-chip configurations stay at 16 (profiles/r04/ab_ds4.txt).
+            const bool has4 = plan->opt.no_four_shift_lanes == 0 &&
+                              sm_bs_kernel_ptr(g.n, 4, true, ghost, false) && nl_for(4, l2) <= 32;
+            double cbest = 0;
+            int dbest = 0;
+            for (int d : {16, 8, 4}) {
+                if (d == 16 && ds != 16) continue;          // (windows whose 16-shift build does not exist)
+                if (d == 8 && !has8) continue;
+                if (d == 4 && !has4) continue;
+                MatchGeom gd;
+                int rd = 0;
+                const double c = configure_best(d, gd, rd);
+                if (!dbest || c < 0.95 * cbest) { dbest = d; cbest = c; }
+            }
+            if (dbest) ds = dbest;
         }
     }
     configure_best(ds, gsel, rws);

@@ -8,16 +8,19 @@
 const void *sm_bs_ptr_ds8(int n, bool fulld, bool ghost, bool cap2);
 const void *sm_bs_ptr_duo(int n, bool fulld, bool ghost);
 const void *sm_bs_ptr_duo8(int n, bool fulld, bool ghost);
+const void *sm_bs_ptr_ds4(int n, bool fulld, bool ghost, bool cap2, bool duo);
 #ifdef SM_STAMPS
 int sm_bs_set_stamps_ds8(void *buf);
 int sm_bs_set_stamps_duo(void *buf);
 int sm_bs_set_stamps_duo8(void *buf);
+int sm_bs_set_stamps_ds4(void *buf);
 extern "C" int sm_debug_set_stamps(void *buf)
 {
     int rc = sm_bs_set_stamps_main(buf);
     if (!rc) rc = sm_bs_set_stamps_ds8(buf);
     if (!rc) rc = sm_bs_set_stamps_duo(buf);
     if (!rc) rc = sm_bs_set_stamps_duo8(buf);
+    if (!rc) rc = sm_bs_set_stamps_ds4(buf);
     return rc;
 }
 #endif
@@ -34,6 +37,7 @@ extern "C" int sm_debug_set_stamps(void *buf)
 // two waves per SIMD wherever the registers would allow three (cap2 is not a choice there).
 const void *sm_bs_kernel_ptr(int n, int ds, bool fulld, bool ghost, bool cap2, bool duo)
 {
+    if (ds == 4) return sm_bs_ptr_ds4(n, fulld, ghost, cap2, duo);
     if (duo) {
         if (cap2) return nullptr;
         return ds == 16 ? sm_bs_ptr_duo(n, fulld, ghost) : ds == 8 ? sm_bs_ptr_duo8(n, fulld, ghost) : nullptr;

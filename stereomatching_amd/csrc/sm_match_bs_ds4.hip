@@ -1,0 +1,26 @@
+// sm_match_bs_ds4.hip -- builds of the bit-sliced kernel with 4 shifts per lane (small windows, for
+// grids that leave the chip mostly empty: a single small pair), one-wave and two-wave workgroups.
+
+#define SM_BS_TU ds4
+#include "sm_match_bs_kernel.h"
+
+const void *sm_bs_ptr_ds4(int n, bool fulld, bool ghost, bool cap2, bool duo)
+{
+    if (duo) {
+        if (cap2) return nullptr;
+        switch (n) {
+        case 3: return bs_ptr4<3, 4, true, true>(fulld, ghost);
+        case 5: return bs_ptr4<5, 4, true, true>(fulld, ghost);
+        case 7: return bs_ptr4<7, 4, true, true>(fulld, ghost);
+        case 9: return bs_ptr4<9, 4, true, true>(fulld, ghost);
+        default: return nullptr;
+        }
+    }
+    switch (n) {
+    case 3: return bs_ptr<3, 4, true>(fulld, ghost, cap2);
+    case 5: return bs_ptr<5, 4, true>(fulld, ghost, cap2);
+    case 7: return bs_ptr<7, 4, true>(fulld, ghost, cap2);
+    case 9: return bs_ptr<9, 4, true>(fulld, ghost, cap2);
+    default: return nullptr;
+    }
+}

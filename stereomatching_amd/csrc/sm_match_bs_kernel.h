@@ -471,7 +471,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
     constexpr int HALF = N / 2;
     constexpr int HB = bits_for(N);             // planes of a horizontal count
     constexpr int SB = bits_for(N * N);         // planes of a window count; 2^SB - 1 > N*N
-    constexpr int AB = DS == 16 ? 4 : 3;        // planes of the in-lane shift index
+    constexpr int AB = DS == 16 ? 4 : DS == 8 ? 3 : 2;   // planes of the in-lane shift index
     constexpr int ABMAX = AB + 6;               // after merging up to 64 lanes
     static_assert(SB <= 16, "window counts are moved through two byte lanes");
     static_assert((1 << SB) - 1 > N * N, "the all-ones marker must not be a real count");

@@ -404,6 +404,7 @@ def test_baseline_config_full_size_properties(hip, cfg):
 # environment variable
 POPCOUNT = dict(kernel_family=1)
 DS8 = dict(shifts_per_lane=8)
+DS4 = dict(shifts_per_lane=4)
 ONE_WAVE, TWO_WAVES = dict(workgroup_waves=1), dict(workgroup_waves=2)
 NO_CAP2 = dict(no_two_wave_cap=1)
 
@@ -412,7 +413,9 @@ NO_CAP2 = dict(no_two_wave_cap=1)
 @pytest.mark.parametrize("w,h,d,sw", [(300, 150, 128, 9), (71, 53, 30, 5), (130, 70, 64, 7), (90, 61, 64, 11)])
 @pytest.mark.parametrize("variant", [POPCOUNT, DS8, dict(tile_h=5), dict(DS8, tile_h=7), NO_CAP2,
                                      ONE_WAVE, dict(ONE_WAVE, tile_h=5), dict(ONE_WAVE, **DS8),
-                                     dict(TWO_WAVES, tile_h=5), dict(TWO_WAVES, tile_h=7, **DS8)])
+                                     dict(TWO_WAVES, tile_h=5), dict(TWO_WAVES, tile_h=7, **DS8),
+                                     DS4, dict(DS4, tile_h=5), dict(ONE_WAVE, **DS4), dict(TWO_WAVES, tile_h=6, **DS4),
+                                     dict(no_four_shift_lanes=1)])
 def test_alternative_kernels_match_oracle(hip, variant, mode, w, h, d, sw):
     """the popcount kernels (general fallback), the 8-shifts-per-lane bit-sliced
     variant and odd tile heights give the same bits as the default path"""
@@ -422,8 +425,12 @@ def test_alternative_kernels_match_oracle(hip, variant, mode, w, h, d, sw):
         assert ("two-wave workgroups" in desc) == (variant["workgroup_waves"] == 2), desc
     if "kernel_family" in variant:
         assert "tiled kernel" in desc
-    elif "shifts_per_lane" in variant and sw in (8, 9):       # the 8-per-lane variant is built for 9x9
+    elif variant.get("shifts_per_lane") == 8 and sw in (8, 9):       # the 8-per-lane variant is built for 9x9
         assert "lanes of 8" in desc
+    elif variant.get("shifts_per_lane") == 4 and sw <= 9:             # 4 per lane: windows up to 9 x 9, D <= 128
+        assert "lanes of 4" in desc
+    elif "no_four_shift_lanes" in variant:
+        assert "lanes of 4" not in desc
     elif "no_two_wave_cap" in variant:              # small grids default to the 2-wave variant
         assert "2 waves/SIMD variant" not in desc
     elif variant.get("workgroup_waves") == 1 and "tile_h" in variant and sw in (5, 7) and "shifts_per_lane" not in variant:
@@ -472,7 +479,7 @@ def test_match_launch_is_deterministic(hip, cfg, pairs):
     plan.close()
 
 
-BUILT_BS = [(n, 16) for n in (3, 5, 7, 9, 11)] + [(n, 8) for n in range(3, 22, 2)]
+BUILT_BS = [(n, 16) for n in (3, 5, 7, 9, 11)] + [(n, 8) for n in range(3, 22, 2)] + [(n, 4) for n in (3, 5, 7, 9)]
 
 
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])

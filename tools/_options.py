@@ -20,6 +20,7 @@ NAMES = {
     "SM_PRIO_CLASS": lambda v: {"priority_class": int(v)},
     "SM_PRIO_ON_CHANGE": lambda v: {"priority_on_change": int(v)},
     "SM_LANE_MERGE": lambda v: {"lane_merge": int(v)},
+    "SM_NO_DS4": lambda v: {"no_four_shift_lanes": int(v)},
 }
 
 
@@ -39,7 +40,8 @@ class PlanOptions(C.Structure):     # sm_plan_options, for tools that load a lib
                 ("shifts_per_lane", C.c_int), ("workgroup_waves", C.c_int), ("no_two_wave_cap", C.c_int),
                 ("priority_pattern", C.c_uint), ("edge_kernel", C.c_int), ("timing_by_records", C.c_int),
                 ("cost_pixels_per_lane", C.c_int), ("cost_tile_h", C.c_int), ("cost_kernel", C.c_int),
-                ("priority_class", C.c_int), ("priority_on_change", C.c_int), ("lane_merge", C.c_int)]
+                ("priority_class", C.c_int), ("priority_on_change", C.c_int), ("lane_merge", C.c_int),
+                ("no_four_shift_lanes", C.c_int)]
 
 
 def struct_from_spec(spec: dict) -> PlanOptions:
