@@ -355,6 +355,7 @@ def c4_leg(rank, world, dev, red_dev, steps, threshold, rehearsal, dryrun):
     got = shard.gather_maps(local.cpu() if rehearsal else local, C4_TOTAL_PAIRS, rank, world)
     torch.cuda.synchronize(dev)
     gather = shard.max_over_ranks(time.perf_counter() - g0, red_dev)
+    plan_text = plan.describe()
     plan.close()
     if rank != 0:
         return None
@@ -363,21 +364,13 @@ def c4_leg(rank, world, dev, red_dev, steps, threshold, rehearsal, dryrun):
         bool(torch.equal(got[j], mine0[(j // world) % min(C4_DISTINCT, share)])) for j in range(C4_TOTAL_PAIRS))
     inbound = (C4_TOTAL_PAIRS - share) * w * h * 4
     obj.update(value=round(float(w) * h * d * C4_TOTAL_PAIRS * steps / elapsed / 1e6, 1),
-               ms_per_step=round(elapsed / steps * 1e3, 4), kernel=plan_desc_short(w, h, d, sw, mode, share, dev),
+               ms_per_step=round(elapsed / steps * 1e3, 4), kernel=plan_text,
                gather_ms=round(gather * 1e3, 3), gather_bytes_inbound=inbound,
                gather_GBps=round(inbound / gather / 1e9, 1) if gather > 0 and inbound else None,
                gather_transport="gloo over host memory (rehearsal)" if rehearsal else
                                 "RCCL point to point (ncclSend / ncclRecv under torch.distributed), maps device to device",
                maps_in_pair_order=bool(ok))
     return obj
-
-
-def plan_desc_short(w, h, d, sw, mode, share, dev):
-    from stereomatching_amd import pipeline
-    p = pipeline.StereoPlan(w, h, d, sw, mode, max_pairs=max(1, share), device=dev.index)
-    text = p.describe()
-    p.close()
-    return text
 
 
 def timing_stride(steps: int) -> int:

@@ -17,6 +17,7 @@
 #include "sm_internal.h"
 
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
@@ -39,6 +40,8 @@ RcclApi g_rccl;
 
 int load_rccl()
 {
+    static std::mutex once;                 // (communicators may be created from several host threads)
+    std::lock_guard<std::mutex> lock(once);
     if (g_rccl.handle) return SM_OK;
     void *h = nullptr;
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
