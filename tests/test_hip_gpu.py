@@ -1385,3 +1385,25 @@ def test_c_abi_rccl_collection_on_one_rank(hip):
     lib.sm_comm_destroy(comm)
     lib.sm_comm_destroy(None)
     plan.close()
+
+
+@pytest.mark.parametrize("flags,graph", [([], True), (["--no-graph"], False)])
+def test_bench_line_with_and_without_graph_replay(flags, graph):
+    """bench.py's two ways of issuing its steps -- replayed from HIP graphs (default; the kernel time is sampled
+    right behind the timed region) and launched from the host (--no-graph; the match launches of the timed
+    region carry their own events) -- give a complete line each, and about the same rate."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "24", "--warmup", "3", "--no-cpu-baseline",
+                        "--no-e2e", "--no-cost-modes", *flags], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][0]
+    assert out["steps"] == 24 and out["value"] > 1e6 and out["roofline"]["bound"] == "valu"
+    assert bool(out["config"]["graph"]) == graph, out["config"]["graph"]
+    assert out["roofline"]["kernel_launches_timed"] >= 10
+    assert 0.3 < out["roofline"]["frac"] < 1.0 and out["roofline"]["kernel_ms"] < out["ms_per_step"]

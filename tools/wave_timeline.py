@@ -46,8 +46,15 @@ assert capi.lib.sm_debug_set_stamps(C.c_void_p(stamps.data_ptr())) == 0
 for rep in range(3):
     stamps.zero_()
     torch.cuda.synchronize()
-    # back to back with a preceding launch of the same kernel, as in the bench loop
+    # back to back with a preceding launch of the same kernel, as in a loop of match launches -- or (WT_STEP=1)
+    # behind the edge kernel, as in the real step: the waves then land in other slots
     plan.match_wta(pairs, want_best=False, web=web)
+    if os.environ.get("WT_STEP"):
+        for _ in range(20):                     # a run of real steps in front, then the stamped one
+            plan.find_all_edges(left, right, want_edges=False)
+            plan.match_wta(pairs, want_best=False, web=web)
+        plan.find_all_edges(left, right, want_edges=False)
+        stamps.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     plan.match_wta(pairs, want_best=False, web=web)
