@@ -427,7 +427,7 @@ def test_alternative_kernels_match_oracle(hip, variant, mode, w, h, d, sw):
         assert "tiled kernel" in desc
     elif variant.get("shifts_per_lane") == 8 and sw in (8, 9):       # the 8-per-lane variant is built for 9x9
         assert "lanes of 8" in desc
-    elif variant.get("shifts_per_lane") == 4 and sw <= 9:             # 4 per lane: windows up to 9 x 9, D <= 128
+    elif variant.get("shifts_per_lane") == 4:                         # 4 per lane: every window, D <= 128
         assert "lanes of 4" in desc
     elif "no_four_shift_lanes" in variant:
         assert "lanes of 4" not in desc
@@ -479,7 +479,7 @@ def test_match_launch_is_deterministic(hip, cfg, pairs):
     plan.close()
 
 
-BUILT_BS = [(n, 16) for n in (3, 5, 7, 9, 11)] + [(n, 8) for n in range(3, 22, 2)] + [(n, 4) for n in (3, 5, 7, 9)]
+BUILT_BS = [(n, 16) for n in (3, 5, 7, 9, 11)] + [(n, 8) for n in range(3, 22, 2)] + [(n, 4) for n in range(3, 22, 2)]
 
 
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
