@@ -151,6 +151,8 @@ typedef struct sm_plan_options {
                                  * 0 = the plan's choice */
     int no_four_shift_lanes;    /* bit-sliced kernel: 1 = never 4 shifts per lane (the plan's own choice is between 16, 8
                                  * and 4); shifts_per_lane = 4 forces them where they are built */
+    int priority_unit_log2;     /* bit-sliced kernel: log2 of the priority schedule's unit in shader-clock cycles (8 .. 20;
+                                 * bit k of priority_pattern covers the k-th unit); 0 = the plan's choice */
 } sm_plan_options;
 int sm_plan_create_ex(int device, int width, int height, int num_shifts, int square_width,
                       int border, int max_pairs, const sm_plan_options *options, sm_plan **out);

@@ -59,6 +59,7 @@ struct MatchGeom {
     int cap2;            // bit-sliced kernel: launch the two-waves-per-SIMD variant
     int duo;             // bit-sliced kernel: two-wave workgroups of 2 * tile_h rows (shared warm-up)
     unsigned prio_pattern;   // bit-sliced kernel: the time-sliced priority schedule (sm_match_bs_kernel.h)
+    int prio_unit;           // ... log2 of the schedule's unit in shader-clock cycles (14: 16384 cycles, ~8 us)
     int prio_shift;          // ... the HW_ID bit that tells a SIMD's two waves apart: 0 wave slot, 16 workgroup slot (TG_ID)
     int prio_on_change;      // ... s_setprio only when the wanted priority changes (else once per row)
     int xmerge;          // bit-sliced kernel: the shift lanes of a word are merged through LDS every 4 rows (nl >= 4)

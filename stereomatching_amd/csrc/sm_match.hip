@@ -505,6 +505,7 @@ int sm_match_configure(sm_plan *plan)
         g.tile_h = g.tw = g.runs = g.nl = g.log2nl = g.threads = g.ds = 0;
         g.plw = g.prw = g.nsr = g.tiles_x = g.tiles_y = g.vec_ok = g.lds_bytes = g.cap2 = g.duo = 0;
         g.prio_pattern = 0;
+        g.prio_unit = 14;
         g.xmerge = g.xm_off = g.xm_words = 0;
         g.prio_shift = 0;
         g.prio_on_change = 0;
@@ -741,7 +742,15 @@ int sm_match_configure(sm_plan *plan)
         g.edge_words_r = std::min(g.ext_words, (g.pad_l + W + g.half + D - 2) / 32 + 1);
     }
     g.prio_pattern = sm_bs_default_pattern(g.duo != 0);
+    g.prio_unit = 14;
+    // The launches of the 8- and 4-shifts-per-lane builds are short (a single small pair: 16 us; the reference's
+    // defaults at 4K: 58 us): with slices of four units (~31 us) the favoured wave of a SIMD pair never or hardly
+    // changes, and the other one finishes alone.  They swap every unit (~8 us): C2's match launch 17.1 -> 15.6 us,
+    // step -4 %; 21 x 21 / 30 shifts at 4K -1..2 %; the long launches (16 shifts per lane) lose 2-3 % with it and
+    // keep the four-unit slices (profiles/r04/ab_prio_unit.txt).
+    if (bs && g.ds < 16) g.prio_pattern = 0xAAAAAAAAu;
     if (plan->opt.priority_pattern) g.prio_pattern = plan->opt.priority_pattern;   // tuning
+    if (plan->opt.priority_unit_log2 >= 8 && plan->opt.priority_unit_log2 <= 20) g.prio_unit = plan->opt.priority_unit_log2;
     // the bit that tells a SIMD's two waves apart (see the kernel): the wave slot.  The workgroup's slot on its
     // CU (priority_class 2) wins 1-2 % (6 % at 21 x 21) when the match launch follows ITSELF, as in a timing loop
     // of match launches -- and LOSES 5 % in the real step, where it follows the edge kernel and its workgroups

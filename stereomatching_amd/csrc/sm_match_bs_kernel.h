@@ -522,14 +522,15 @@ __global__ __launch_bounds__(DUO ? 128 : 64, SM_BS_WAVES) void k_match_bs(const 
     // slices counted from the wave's own start (the waves of a launch start within 0.5 us of
     // each other): bit k of the plan's pattern (g.prio_pattern: SM_BS_PATTERN unless SM_PATTERN
     // in the environment overrides it for tuning) says which slot parity is favoured during
-    // the k-th 16384-cycle unit, so the schedule is the same in every launch
+    // the k-th unit of 2^g.prio_unit cycles (16384, ~8 us; short launches take finer ones), so the schedule is the
+    // same in every launch
     const unsigned long long clk0 = clk;
     // (g.prio_on_change, tuning: s_setprio only when the wanted priority changes instead of once per row --
     // on part of the pool a wave that re-issues it every row is served as if it had none)
     unsigned prio_now = 2;
 #define SM_SLICE_PRIO()                                                               \
     do {                                                                              \
-        const unsigned unit_ = (unsigned)((clk - clk0) >> 14) & 31u;                  \
+        const unsigned unit_ = (unsigned)((clk - clk0) >> g.prio_unit) & 31u;         \
         const unsigned want_ = ((g.prio_pattern >> unit_) ^ slot_parity) & 1;         \
         if (!g.prio_on_change || want_ != prio_now) {                                 \
             if (want_) __builtin_amdgcn_s_setprio(3);                                 \
