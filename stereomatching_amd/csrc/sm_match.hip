@@ -586,8 +586,11 @@ int sm_match_configure(sm_plan *plan)
                    (plan->opt.lane_merge == 2 || ((ds == 16 || ds == 4) && o.log2nl >= 3));
         // lane-row work relative to ds = 16: the per-row shared views and the merge levels weigh more the fewer
         // shifts a lane carries (fitted to same-device timings: profiles/r02/ds8_small_grids_sweep.txt, r04/ab_ds4.txt)
-        const double work = ds == 16 ? 1.0 : ds == 8 ? 0.5 * 1.10
-                          : o.xmerge ? 0.25 * 1.43 : 0.25 * (1.30 + 0.15 * o.log2nl);
+        // (round 4, tools/ds_choice_check.py over 14 shapes: 8 shifts per lane was the best of the three ONCE and
+        // was chosen seven times -- its weight went from 0.55 to 0.65, the LDS-merged 4-shift build's from 0.36 to
+        // 0.33, and a 16-shift row whose lanes are merged through LDS counts 0.95)
+        const double work = ds == 16 ? (o.xmerge ? 0.95 : 1.0) : ds == 8 ? 0.5 * 1.30
+                          : o.xmerge ? 0.25 * 1.32 : 0.25 * (1.30 + 0.15 * o.log2nl);
         const int mb_words = o.xmerge ? npg * 1024 : 0;
         auto lds_words = [&](int th, int &xm_off) {
             const int staged = ((rows_per_wg * th + o.n - 1) * rows_words + 3) & ~3;
@@ -715,13 +718,20 @@ int sm_match_configure(sm_plan *plan)
             // waves (less warm-up per output row).  The cost model decides, with 5 % in favour of the wider
             // lane.  Measured: C2 29.6 (16) -> 19.1 (8) -> 16.5 us (4, lanes merged through LDS), C1 18.4 ->
             // 9.8 -> 7.2 us; the full-chip configurations stay at 16 (profiles/r04/ab_ds4.txt).
-            const bool has4 = plan->opt.no_four_shift_lanes == 0 &&
+            // What the model cannot see -- the narrow lanes win by latency hiding on grids that leave the chip
+            // partly empty, not by instruction count -- is put in as a rule taken from tools/ds_choice_check.py
+            // (14 shapes, profiles/r04/ds_choice_*.txt): below 0.3 G pixel-shifts per launch, or for windows of
+            // 13 x 13 and more (their warm-up weighs less on narrow, tall tiles), all three are candidates; above
+            // it a window that has a 16-shift build takes it (the worst miss of this rule: 5 %).
+            const double pxshifts = (double)W * H * D * plan->max_pairs;
+            const bool small_or_tall = pxshifts <= 0.3e9 || g.n >= 13;
+            const bool has4 = plan->opt.no_four_shift_lanes == 0 && small_or_tall &&
                               sm_bs_kernel_ptr(g.n, 4, true, ghost, false) && nl_for(4, l2) <= 32;
             double cbest = 0;
             int dbest = 0;
             for (int d : {16, 8, 4}) {
                 if (d == 16 && ds != 16) continue;          // (windows whose 16-shift build does not exist)
-                if (d == 8 && !has8) continue;
+                if (d == 8 && (!has8 || (ds == 16 && !small_or_tall))) continue;
                 if (d == 4 && !has4) continue;
                 MatchGeom gd;
                 int rd = 0;
