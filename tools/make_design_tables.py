@@ -16,7 +16,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
+tag = args_[0] if args_ else "r04"
 P = ROOT / "profiles" / tag
 
 
@@ -143,10 +144,16 @@ if d:
         out += ["", "Extras of the default line: " + "; ".join(ex) + "."]
 
 text = "\n".join(out) + "\n"
-(P / "RESULTS.md").write_text(text)
 design = ROOT / "DESIGN.md"
 src = design.read_text()
 pat = re.compile(r"(<!-- GENERATED:results BEGIN[^\n]*-->\n).*?(<!-- GENERATED:results END -->)", re.S)
 assert pat.search(src), "DESIGN.md has no GENERATED:results block"
+if "--check" in sys.argv:
+    # (tests/test_docs_cpu.py: the block in DESIGN.md and profiles/<tag>/RESULTS.md are what the files say)
+    cur = pat.search(src).group(0).split("-->\n", 1)[1].rsplit("<!-- GENERATED:results END -->", 1)[0]
+    ok = cur == text and (P / "RESULTS.md").read_text() == text
+    print("DESIGN.md's generated block is up to date" if ok else "DESIGN.md's generated block is STALE: run tools/make_design_tables.py")
+    sys.exit(0 if ok else 1)
+(P / "RESULTS.md").write_text(text)
 design.write_text(pat.sub(lambda m: m.group(1) + text + m.group(2), src))
 print(text)
