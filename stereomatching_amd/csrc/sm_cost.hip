@@ -345,7 +345,8 @@ extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint
             // workgroups, 50-60 us at 4K -- BESIDE the main launch on a stream of its own, the two writing
             // disjoint columns: the main launch then takes 130 us longer at C5 SAD, 881 vs 754 us, and 23 us at
             // C5 SSD -- the strip's 256-thread workgroups take their CUs' LDS and wave slots first and the main
-            // launch's one-wave workgroups no longer spread evenly.  profiles/r04/ab_cost_strip_beside_rejected.txt)
+            // launch's one-wave workgroups no longer spread evenly; enqueued behind the main launch instead of in front
+            // of it, the same: 876 vs 754 us.  profiles/r04/ab_cost_strip_beside_rejected.txt)
             if (q.ghost && plan->square_width / 2 > 0)
                 return launch_general(plan, d_gray_left, d_gray_right, cost, pairs, d_web, d_best,
                                       plan->square_width / 2, (hipStream_t)stream);
