@@ -16,6 +16,7 @@ struct SadGeom {
     int q_tail;              // first quad of a lane that may hold shifts >= D
     int q_last;              // last quad in which some lane has a shift < D
     int fast_stage;          // image rows are dword-aligned and w % 4 == 0
+    int rr_stride;           // SSD: dwords between the four residue classes of the RR table (sm_cost_ssd.hip)
     int lds_bytes;
 };
 
@@ -24,8 +25,9 @@ struct SadGeom {
 // bytes of the left image then [nsr][rrow] of the right one, byte 0 of a staged row = image column
 // xw - padl, with the border rule applied: wrap-around (toroidal) or zeros outside the image (ghost).
 // One-wave workgroups (tid < 64).  Shared by the SAD and the SSD kernel.
+// `flip` is XORed onto every staged dword (the SSD kernel stages pixel - 128 as signed bytes: 0x80808080).
 __device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ L, const u8 *__restrict__ R,
-                                               const SadGeom &g, int xw, int ty0, int HALF, int tid)
+                                               const SadGeom &g, int xw, int ty0, int HALF, int tid, u32 flip = 0)
 {
     const int lw = g.lrow >> 2, rw = g.rrow >> 2;
     if (g.fast_stage) {
@@ -69,7 +71,7 @@ __device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ 
             for (int r = 0; r < SR; r++)
 #pragma unroll
                 for (int c = 0; c < SC; c++)
-                    if (dst[c] >= 0 && row0 + r < g.nsr) lds[dst[c] + (row0 + r) * dstride[c]] = v[r][c];
+                    if (dst[c] >= 0 && row0 + r < g.nsr) lds[dst[c] + (row0 + r) * dstride[c]] = v[r][c] ^ flip;
         }
     } else {
         for (int row = 0; row < g.nsr; row++) {
@@ -89,7 +91,7 @@ __device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ 
                     else p = src[((xb % g.w) + g.w) % g.w];
                     v |= p << (8 * b);
                 }
-                (is_r ? lds + g.nsr * lw + row * rw : lds + row * lw)[kk] = v;
+                (is_r ? lds + g.nsr * lw + row * rw : lds + row * lw)[kk] = v ^ flip;
             }
         }
     }

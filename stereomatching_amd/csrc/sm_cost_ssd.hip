@@ -9,6 +9,7 @@
 //     t  = dot4(left group, right group of the row that slides out, ...)       NG = ceil(n/4) x v_dot4_u32_u8
 //     LR = dot4(left group, right group of the row that slides in, LR) - t     NG + 1
 //     -key = (LR << 9) - (RR[x + d] << 8) - shift    key = (RR - 2 LR) << 8 | shift: signed, first shift wins
+//     best = max3(best, -key of an even quad, -key of the odd quad behind it)
 // The last group of a window row holds n mod 4 pixels: the other bytes of the LEFT operand are
 // zeroed and their products vanish -- no correction term (as the SAD kernel needs) exists here.
 //
@@ -29,7 +30,15 @@
 #include "sm_cost.h"
 #include <type_traits>
 
+#ifndef SSD_SIGNED
+#define SSD_SIGNED 1
+#endif
+#if SSD_SIGNED
+// signed bytes (pixel - 128, staged that way): v_dot4c_i32_i8
+__device__ __forceinline__ u32 dot4(u32 a, u32 b, u32 acc) { return (u32)__builtin_amdgcn_sdot4((int)a, (int)b, (int)acc, false); }
+#else
 __device__ __forceinline__ u32 dot4(u32 a, u32 b, u32 acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
+#endif
 
 template <int N, int PX, bool FULLD>
 __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, const u8 *__restrict__ right,
@@ -53,17 +62,20 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
     const int lw = g.lrow >> 2, rw = g.rrow >> 2;                    // dwords per staged row
     u32 *sL = lds;                                                   // [nsr][lw]
     u32 *sR = sL + g.nsr * lw;                                       // [nsr][rw]
-    // -(RR << 8) of the current output row by right byte position (the window centre), flat: negated and shifted
-    // once per position where it is updated, not 44 times per lane and row where it is read.  The lanes of a wave
-    // that differ in their shift-lane read entries 32 apart -- the same bank: 8-way conflicts on the 44
-    // reads of a lane and row at 256 shifts.  An interleaved [position][shift-lane] table removes them
-    // (178 M -> 21 M conflict cycles at C5) and was measured SLOWER, 1.32 vs 1.22 ms: keeping it
-    // up to date takes 3 600 LDS cycles per wave and row (quad writes are 13 cycles each) against the
-    // 700 the conflicts cost, in four dependent LDS round trips (profiles/r03/ab_ssd_rr_phase.txt).
-    u32 *sRR = sR + g.nsr * rw;                                      // [rrow]
+    // -(RR << 8) of the current output row by right byte position q (the window centre): negated and shifted
+    // once per position where it is updated, not 44 times per lane and row where it is read.  Position q lives at
+    // dword (q & 3) * rr_stride + (q >> 2): the lanes of a half-wave that differ in their shift-lane read positions
+    // 32 apart, in a flat table the same bank (4-way conflicts on the 44 reads of a lane and row); split by
+    // residue the four shift-lanes of a half-wave are 8 dwords apart and the four residues rr_stride = 5 mod 8
+    // apart: 2-way, the floor for 32 lanes whose dword addresses span 16 banks' worth of distinct values.  (A
+    // table interleaved [position][shift-lane] removes the conflicts altogether and was measured SLOWER in
+    // round 3, 1.32 vs 1.22 ms: keeping it up to date takes 3 600 LDS cycles per wave and row against the 700
+    // the conflicts cost, profiles/r03/ab_ssd_rr_phase.txt.  The split table is a permutation: no extra update.)
+    u32 *sRR = sR + g.nsr * rw;                                      // [4][rr_stride]
+    const int S = g.rr_stride;
 
-    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid);
-    for (int r = tid; r < g.rrow; r += 64) sRR[r] = 0;
+    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid, SSD_SIGNED ? 0x80808080u : 0u);
+    for (int r = tid; r < 4 * S; r += 64) sRR[r] = 0;
     __syncthreads();
 
     // ---- lane role: residue a, shift-lane sl, pixel group j
@@ -78,14 +90,19 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
     const int rho = (a - HALF) & 3;                     // (x - HALF) mod 4
     const int bL = (x0 - HALF - rho - (xw - g.padl)) >> 2;      // dword of the window's aligned start
     const int bR = bL + NQ * sl;                        // ... of the lane's first shift (32 sl)
-    const int r0 = x0 - (xw - g.padl) + 4 * NQ * sl;    // RR entry of (pixel 0, shift 32 sl)
+    // RR entry of (pixel p, shift 32 sl + 4 m + i): position r0 + 4 (p + m) + i, r0 = x0 - (xw - padl) + 32 sl, whose
+    // residue is (a + i) & 3 for every p and m: dword rrb[i] + p + m
+    const int r0w = (x0 - a - (xw - g.padl) + 4 * NQ * sl) >> 2;
+    int rrb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) rrb[i] = ((a + i) & 3) * S + r0w + ((a + i) >> 2);
     const int dlim = g.D - 4 * NQ * sl;                 // this lane's shifts below D
 
     u32 A[PX][NQ][4];            // LR window sums of (pixel, quad, shift within the quad)
     u32 LLs[PX];
 #pragma unroll
     for (int p = 0; p < PX; p++) {
-        LLs[p] = 0;
+        LLs[p] = 0;             // (signed build: LL - 2 C, see the step)
 #pragma unroll
         for (int m = 0; m < NQ; m++)
 #pragma unroll
@@ -117,7 +134,8 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                     so = dot4(u, u, so);
                 }
             }
-            sRR[4 * k + HALF + i] -= (sn - so) << 8;       // the table holds -(RR << 8): what the keys take
+            const int q = 4 * k + HALF + i;
+            sRR[(q & 3) * S + (q >> 2)] -= (sn - so) << 8;       // the table holds -(RR << 8): what the keys take
         }
         __syncthreads();
 #endif
@@ -150,7 +168,13 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
             for (int gp = 0; gp < NG; gp++) {
                 const u32 v = gp == FG ? unp[p] : un[p + gp];
                 sn = dot4(v, v, sn);
-                if (!WARM) { const u32 u = gp == FG ? uop[p] : uo[p + gp]; so = dot4(u, u, so); }
+                if (!WARM) {
+                    const u32 u = gp == FG ? uop[p] : uo[p + gp];
+                    so = dot4(u, u, so);
+#if SSD_SIGNED
+                    so = dot4(u, 0x02020202u, so);      // + 2 x the old row's sum: the drift C of the LR sums, see below
+#endif
+                }
             }
             LLs[p] += sn - so;
         }
@@ -175,6 +199,13 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
             if (!WARM) {
 #pragma unroll
                 for (int k = 0; k < K + 2; k++) t[k] = rowRo[bR + k];
+#if SSD_SIGNED
+                // the old row's right operand COMPLEMENTED: as signed bytes ~r = -r - 1, so its v_dot4 SUBTRACTS the old
+                // row's products (and the old row's left pixels once each, a drift C that is the same for every
+                // shift of a pixel -- it cannot change the arg-min and comes off `best` through LLs)
+#pragma unroll
+                for (int k = 0; k < K + 2; k++) t[k] = ~t[k];
+#endif
 #pragma unroll
                 for (int k = 0; k <= K; k++) wo[k] = __builtin_amdgcn_alignbyte(t[k + 1], t[k], rho);
             }
@@ -189,21 +220,44 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                 if (!WARM) ro[k] = i ? __builtin_amdgcn_alignbyte(wo[k + 1], wo[k], i) : wo[k];
             }
             // RR of (pixel p, shift 4 m + i) is entry r0 + 4 (p + m) + i: a window of PX entries slides over m
-            u32 nrr[PX + 1];            // -(RR << 8) of the window's entries
+            // -(RR << 8) of the window's entries, each MINUS its own offset 4 k + i from the lane's first entry
+            // (k = p + m): that offset is the shift 4 m + i of pixel p plus 4 p, so the low byte of a key tells the
+            // shift apart as before, and the subtraction is done once per entry (PX + NQ - 1 of them) instead of
+            // once per (pixel, shift); the 4 p come off with the shift-lane's base at the end of the row
+            u32 nrr[PX + 1];
             if (OUT) {
 #pragma unroll
-                for (int p = 0; p < PX; p++) nrr[p] = sRR[r0 + 4 * p + i];
+                for (int p = 0; p < PX; p++) nrr[p] = sRR[rrb[i] + p] - (u32)(4 * p + i);
             }
+            i32 held[PX];               // the keys of an even quad wait for the odd one's: one v_max3_i32 for two
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < NQ; m++) {
-                if (OUT && m + 1 < NQ) nrr[PX] = sRR[r0 + 4 * (PX + m) + i];
+                if (OUT && m + 1 < NQ) nrr[PX] = sRR[rrb[i] + PX + m] - (u32)(4 * (PX + m) + i);
                 // the PX pixels' chains side by side, group by group: a v_dot4 that accumulates onto the one
                 // issued just before it costs a wait state (three before any other reader), and the compiler
                 // pads with s_nop what the source order does not separate
-                u32 t[PX], acc[PX];
+                u32 acc[PX];
 #pragma unroll
-                for (int p = 0; p < PX; p++) { t[p] = 0; acc[p] = A[p][m][i]; }
+                for (int p = 0; p < PX; p++) acc[p] = A[p][m][i];
+#if SSD_SIGNED
+                // one chain per pixel: the old row's groups against the complemented right row take their products off
+                if (!WARM) {
+#pragma unroll
+                    for (int gp = 0; gp < NG; gp++)
+#pragma unroll
+                        for (int p = 0; p < PX; p++) acc[p] = dot4(gp == FG ? uop[p] : uo[p + gp], ro[p + m + gp], acc[p]);
+                }
+#pragma unroll
+                for (int gp = 0; gp < NG; gp++)
+#pragma unroll
+                    for (int p = 0; p < PX; p++) acc[p] = dot4(gp == FG ? unp[p] : un[p + gp], rn[p + m + gp], acc[p]);
+#pragma unroll
+                for (int p = 0; p < PX; p++) A[p][m][i] = acc[p];
+#else
+                u32 t[PX];
+#pragma unroll
+                for (int p = 0; p < PX; p++) t[p] = 0;
                 if (!WARM) {
 #pragma unroll
                     for (int gp = 0; gp < NG; gp++)
@@ -216,6 +270,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                     for (int p = 0; p < PX; p++) acc[p] = dot4(gp == FG ? unp[p] : un[p + gp], rn[p + m + gp], acc[p]);
 #pragma unroll
                 for (int p = 0; p < PX; p++) { acc[p] -= t[p]; A[p][m][i] = acc[p]; }
+#endif
                 if (OUT) {
                     // key = (RR - 2 LR) << 8 | shift within the lane, signed: the smallest wins, i.e. the lowest
                     // SSD (LL is the same for all shifts of a pixel) and among equals the first shift.  Formed
@@ -225,16 +280,19 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                     // the compiler gives its own instructions -- wrong first rows of every tile.)
 #pragma unroll
                     for (int p = 0; p < PX; p++) {
-                        i32 nkey = (i32)((acc[p] << 9) + (nrr[p] - (u32)(4 * m + i)));
+                        i32 nkey = (i32)((acc[p] << 9) + nrr[p]);
                         // FULLD: the lanes' 32 shifts each are all below D (D = 32 x shift-lanes); otherwise the
                         // last shift-lane holds shifts >= D, which must never win
                         if (!FULLD && 4 * m + i >= dl) nkey = (i32)0x80000100;
-                        run[p] = max(run[p], nkey);
+                        if (m & 1) run[p] = max(max(run[p], held[p]), nkey);
+                        else held[p] = nkey;
                     }
+                    if (m & 1) {
 #pragma unroll
-                    for (int p = 0; p < PX; p++)
-                        asm volatile("" : : "v"(run[p]));   // (a use here: the maxima are otherwise deferred to the
-                                                            // row's end and every key kept alive until then)
+                        for (int p = 0; p < PX; p++)
+                            asm volatile("" : : "v"(run[p]));   // (a use here: the maxima are otherwise deferred to the
+                                                                // row's end and every key kept alive until then)
+                    }
                 }
                 if (OUT) {
 #pragma unroll
@@ -247,7 +305,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
         if (OUT) {
 #pragma unroll
             for (int p = 0; p < PX; p++) {
-                i32 key = 4 * NQ * sl - run[p];             // back to the key; its low 8 bits become the shift itself
+                i32 key = 4 * NQ * sl - 4 * p - run[p];     // back to the key; its low 8 bits become the shift itself
                 for (int k = 0; k < g.log2nl; k++) key = min(key, __shfl_xor(key, (4 << jb) << k));
                 const int x = x0 + 4 * p;
                 if (sl == 0 && x < g.w) {
@@ -305,10 +363,13 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
     g.rrow = 8 * ((g.padl + g.tw + 4 * (g.nl * nql + ng + 3) + 7) / 8);
     g.q_tail = g.D - 4 * nql * (g.nl - 1);          // shifts of the last shift-lane below D
     g.q_last = nql - 1;
+    g.rr_stride = g.rrow / 4 + 1;
+    while (g.rr_stride % 8 != 5) g.rr_stride++;
+    const size_t rr_bytes = 16 * (size_t)g.rr_stride;
     const int slots = 256 * 4 * 2;
     int best_th = 0; double best_cost = 0;
     for (int th = 8; th <= 128; th += 4) {
-        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)g.rrow;
+        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + rr_bytes;
         if (lds > 160 * 1024 / 8) break;
         const long long tiles = (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs;
         const long long rounds = (tiles + slots - 1) / slots;
@@ -318,14 +379,14 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
     if (!best_th) return nullptr;
     if (plan->opt.cost_tile_h > 0) {         // an explicit tile height, clamped to what a workgroup's LDS holds
         best_th = plan->opt.cost_tile_h;
-        while (best_th > 1 && (size_t)(best_th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)g.rrow > 64 * 1024) best_th--;
+        while (best_th > 1 && (size_t)(best_th + n - 1) * (g.lrow + g.rrow) + rr_bytes > 64 * 1024) best_th--;
     }
     g.tile_h = best_th < g.h ? best_th : g.h;
     g.tiles_y = (g.h + g.tile_h - 1) / g.tile_h;
     g.nsr = g.tile_h + n - 1;
     g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0 &&
                    g.lrow + g.rrow <= 4 * 256;
-    g.lds_bytes = g.nsr * (g.lrow + g.rrow) + 4 * g.rrow;
+    g.lds_bytes = g.nsr * (g.lrow + g.rrow) + (int)rr_bytes;
     g.nql = nql; g.px = px;
     const bool fulld = g.D == 4 * nql * g.nl;
     const void *fn = nullptr;
