@@ -16,7 +16,8 @@ struct SadGeom {
     int q_tail;              // first quad of a lane that may hold shifts >= D
     int q_last;              // last quad in which some lane has a shift < D
     int fast_stage;          // image rows are dword-aligned and w % 4 == 0
-    int rr_stride;           // SSD: dwords between the four residue classes of the RR table (sm_cost_ssd.hip)
+    int rr_stride;           // SSD: dwords between the four residue classes of the RR table (sm_cost_ssd.hip);
+                             // sm_cost_mfma.hip: dwords of padding in front of its table
     int lds_bytes;
 };
 
@@ -98,6 +99,7 @@ __device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ 
 }
 #endif
 
-// sm_cost_qs.hip / sm_cost_ssd.hip: fill *g and return the kernel for this plan, or nullptr if the shape is not built
+// sm_cost_qs.hip / sm_cost_ssd.hip / sm_cost_mfma.hip: fill *g and return the kernel for this plan, or nullptr if the shape is not built
 const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
 const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
+const void *sm_ssd_mfma_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);

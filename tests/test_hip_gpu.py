@@ -793,7 +793,7 @@ SAD_QS = [  # (w, h, D, S): quads per lane / shift-lanes / pixels per lane of th
 @pytest.mark.parametrize("cost", ["sad", "ssd"])
 @pytest.mark.parametrize("w,h,d,sw", SAD_QS)
 def test_quad_sad_kernel_matches_own_oracle(hip, mode, tile_h, cost, w, h, d, sw):
-    """k_sad_qs / k_ssd_dot: every shape of (quads per lane, shift-lanes), windows 3 .. 21 (SAD from 17 on with
+    """k_sad_qs / k_ssd_mfma / k_ssd_dot: every shape of (quads per lane, shift-lanes), windows 3 .. 21 (SAD from 17 on with
     two packed sums per shift; SSD: .. 11, the larger ones take the general kernel), both borders, tiles of 3 rows (several slides per wave, a
     ragged last tile) and the plan's own height, unaligned input"""
     left, right = make_pair(w, h, d, seed=w * 3 + d, kind="noise" if (w + d) % 3 == 0 else "scene")
@@ -809,6 +809,11 @@ def test_quad_sad_kernel_matches_own_oracle(hip, mode, tile_h, cost, w, h, d, sw
     web2, best2 = gen.cost_wta(dev(left), dev(right), cost)
     assert torch.equal(web2, web) and torch.equal(best2, best)
     plan.close(); gen.close()
+    if cost == "ssd":           # the plan's choice is the matrix-core kernel (k_ssd_mfma); the byte-dot kernel on request
+        dot = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_kernel=2, cost_tile_h=tile_h))
+        web3, best3 = dot.cost_wta(dev(left), dev(right), cost)
+        assert torch.equal(web3, web) and torch.equal(best3, best)
+        dot.close()
 
 
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
@@ -876,7 +881,8 @@ def test_cost_kernels_random_shapes_match_own_oracle(hip):
         if case % 4 == 0:
             left[rng.random((h, w)) < 0.2] = 0
             right[rng.random((h, w)) < 0.2] = 255
-        plan = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_tile_h=th))
+        ck = 2 if cost == "ssd" and case % 3 == 1 else 0         # SSD: a third of the cases on the byte-dot kernel
+        plan = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_tile_h=th, cost_kernel=ck))
         web, best = plan.cost_wta(dev(left), dev(right), cost)
         ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, cost)
         assert np.array_equal(host(web)[0], ow), (case, w, h, d, sw, mode, cost, th)
