@@ -103,3 +103,6 @@ __device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ 
 const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
 const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
 const void *sm_ssd_mfma_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
+// sm_cost_strip.hip: the ghost-border columns x < half behind a fast kernel's launch; -1 if not built for this shape
+int sm_cost_strip_launch(const sm_plan *plan, const uint8_t *d_left, const uint8_t *d_right, int cost, int pairs,
+                         int32_t *d_web, int32_t *d_best, hipStream_t stream);

@@ -349,9 +349,14 @@ extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint
             // C5 SSD -- the strip's 256-thread workgroups take their CUs' LDS and wave slots first and the main
             // launch's one-wave workgroups no longer spread evenly; enqueued behind the main launch instead of in front
             // of it, the same: 876 vs 754 us.  profiles/r04/ab_cost_strip_beside_rejected.txt)
-            if (q.ghost && plan->square_width / 2 > 0)
+            if (q.ghost && plan->square_width / 2 > 0) {
+                // sm_cost_strip.hip: a kernel built for these columns (~10 us at 4K where the general one needs 50-60)
+                const int rc = sm_cost_strip_launch(plan, d_gray_left, d_gray_right, cost, pairs, d_web, d_best,
+                                                    (hipStream_t)stream);
+                if (rc >= 0) return rc;
                 return launch_general(plan, d_gray_left, d_gray_right, cost, pairs, d_web, d_best,
                                       plan->square_width / 2, (hipStream_t)stream);
+            }
             return SM_OK;
         }
     }

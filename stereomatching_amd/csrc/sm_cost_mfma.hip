@@ -123,13 +123,23 @@ __global__ __launch_bounds__(64, 2) void k_ssd_mfma(const u8 *__restrict__ left,
             }
         }
 
+        // (the right row's dwords are requested PF blocks ahead: between the scheduling barriers that keep the
+        // register count down nothing else hides the LDS latency)
+        constexpr int PF = 2;
+        u32 tq[PF + 1][5];
+#pragma unroll
+        for (int b = 0; b < PF && b < NB; b++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) tq[b][k] = rowR[8 * b + k];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             // A operand: 16 bytes of the right row from position 32 b + xl's window start
-            u32 t[5];
-            v4i aop;
+            if (b + PF < NB) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) t[k] = rowR[8 * b + k];
+                for (int k = 0; k < 5; k++) tq[(b + PF) % (PF + 1)][k] = rowR[8 * (b + PF) + k];
+            }
+            const u32 *t = tq[b % (PF + 1)];
+            v4i aop;
 #pragma unroll
             for (int k = 0; k < 4; k++) aop[k] = (int)__builtin_amdgcn_alignbyte(t[k + 1], t[k], rho);
             acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop, bop, acc[b], 0, 0, 0);
@@ -148,15 +158,20 @@ __global__ __launch_bounds__(64, 2) void k_ssd_mfma(const u8 *__restrict__ left,
 
         if (OUT) {
             i32 run0 = NONE, run1 = NONE;               // positions 0..255 (blocks 0..7) and 256.. (block 8)
+            v4i eq[2][4];                               // the table entries of a block, requested one block ahead
+#pragma unroll
+            for (int q = 0; q < 4; q++) eq[0][q] = *reinterpret_cast<const v4i *>(sT + 8 * q + 4 * h);
 #pragma unroll
             for (int b = 0; b < NB; b++) {
+                if (b + 1 < NB) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) eq[(b + 1) & 1][q] = *reinterpret_cast<const v4i *>(sT + 32 * (b + 1) + 8 * q + 4 * h);
+                }
                 i32 keys[16];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const v4i e = *reinterpret_cast<const v4i *>(sT + 32 * b + 8 * q + 4 * h);
+                for (int q = 0; q < 4; q++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) keys[4 * q + j] = (i32)(((u32)acc[b][4 * q + j] << 9) + (u32)e[j]);
-                }
+                    for (int j = 0; j < 4; j++) keys[4 * q + j] = (i32)(((u32)acc[b][4 * q + j] << 9) + (u32)eq[b & 1][q][j]);
                 // The band: block 0 holds shifts < 0 (position 8 q + 4 h + j left of the pixel, 8 q + j < lo), the last
                 // block -- and the one before it unless D is a multiple of 32 -- shifts >= D (32 b + 8 q + j >= hi).
                 // For D a multiple of 32 the last block's bad positions are exactly block 0's good ones.

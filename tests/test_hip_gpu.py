@@ -809,6 +809,11 @@ def test_quad_sad_kernel_matches_own_oracle(hip, mode, tile_h, cost, w, h, d, sw
     web2, best2 = gen.cost_wta(dev(left), dev(right), cost)
     assert torch.equal(web2, web) and torch.equal(best2, best)
     plan.close(); gen.close()
+    if mode == "ghost":         # the border strip x < half: k_cost_strip by default, the general masked kernel on request
+        old = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_kernel=3, cost_tile_h=tile_h))
+        web4, best4 = old.cost_wta(dev(left), dev(right), cost)
+        assert torch.equal(web4, web) and torch.equal(best4, best)
+        old.close()
     if cost == "ssd":           # the plan's choice is the matrix-core kernel (k_ssd_mfma); the byte-dot kernel on request
         dot = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_kernel=2, cost_tile_h=tile_h))
         web3, best3 = dot.cost_wta(dev(left), dev(right), cost)
