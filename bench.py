@@ -57,6 +57,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz max clock, a wave64 VALU
 # instruction issues over 2 cycles -> wave-instructions per second, whole chip
 VALU_PEAK_GIPS = 256 * 4 * 2.4 / 2.0 * 1.0      # = 1228.8 G wave-instr/s
+MFMA_I8_PEAK_TOPS = 5000.0                       # dense int8 on the matrix cores: 2 x the dense bf16 peak (MI355X_MICROARCH.md: "2x BF16 per clock")
 # What the integer VALU of this part SUSTAINS (measured, tools/ubench_sad.hip -> profiles/r03/ubench_sad.txt,
 # launches of the match kernel's length): a stream of 15 v_bitop3 + 1 v_alignbit -- the bit-sliced kernel's
 # mix -- at the two waves per SIMD its registers allow issues 806 G wave-instr/s chip-wide (a pure v_bitop3
@@ -266,6 +267,13 @@ def cost_modes(dev):
                              "valu_wave_instructions_per_launch": c["valu_wave_instructions"],
                              "lane_instructions_per_pixel_shift": round(c["valu_wave_instructions"] * 64.0 / (float(w) * h * d), 2),
                              "source": c.get("source")}
+            if c.get("mfma_i8_instructions"):
+                # the SSD kernel's products run on the matrix cores (v_mfma_i32_32x32x32_i8, 65 536 operations each);
+                # peak: 2 x the guide's dense bf16 figure.  The launch is bound by the VALU / LDS work of ranking the
+                # products, not by the matrix pipe -- this says how idle that pipe is.
+                tops = c["mfma_i8_instructions"] * 65536.0 / (ms * 1e-3) / 1e12
+                o["roofline"]["mfma"] = {"instructions_per_launch": c["mfma_i8_instructions"], "achieved": round(tops, 1),
+                                         "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4)}
         res[key] = o
         plan.close()
     return res

@@ -41,8 +41,17 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ u32 sdot4(u32 a, u32 b, u32 acc) { return (u32)__builtin_amdgcn_sdot4((int)a, (int)b, (int)acc, false); }
 
+// waves per SIMD the register count allows: the NB x 16 accumulators are most of it
+#ifndef MFMA_W3
+#define MFMA_W3 5
+#endif
+#ifndef MFMA_W4
+#define MFMA_W4 3
+#endif
+constexpr int mfma_waves(int nb) { return nb <= MFMA_W4 ? 4 : nb <= MFMA_W3 ? 3 : 2; }
+
 template <int N, int NB>
-__global__ __launch_bounds__(64, 2) void k_ssd_mfma(const u8 *__restrict__ left, const u8 *__restrict__ right,
+__global__ __launch_bounds__(64, mfma_waves(NB)) void k_ssd_mfma(const u8 *__restrict__ left, const u8 *__restrict__ right,
                                                     i32 *__restrict__ web, i32 *__restrict__ best,
                                                     const SadGeom g)
 {
@@ -92,17 +101,22 @@ __global__ __launch_bounds__(64, 2) void k_ssd_mfma(const u8 *__restrict__ left,
         for (int r = 0; r < 16; r++) acc[b][r] = 0;
     i32 LLs = 0;
 
-    // one window row in (rn_i), one out (ro_i; none while WARM), optionally the arg-min of row y
-    auto step = [&](auto warm_tag, auto out_tag, int rn_i, int ro_i, int y) {
-        constexpr bool WARM = decltype(warm_tag)::value, OUT = decltype(out_tag)::value;
+    // One pass over the NB blocks does two rows' work, block by block: the arg-min of the row the accumulators
+    // hold (KEYS: row yk), then the next window row in (FEED: staged row rn_i enters, ro_i leaves unless WARM).
+    // Block b's keys read its accumulators and table entries just before block b's MFMA and table update
+    // change them, so the matrix pipe works on row y + 1 while the VALU ranks row y, and a block's result is
+    // not asked for until a whole pass later.
+    auto step = [&](auto keys_tag, auto feed_tag, auto warm_tag, int rn_i, int ro_i, int yk) {
+        constexpr bool KEYS = decltype(keys_tag)::value, FEED = decltype(feed_tag)::value, WARM = decltype(warm_tag)::value;
         const int rsel = h ? ro_i : rn_i;               // lanes 0..31 feed the entering row, 32..63 the leaving one
         const u32 *rowL = sL + rsel * lw + bw, *rowR = sR + rsel * rw + bw;
         const bool live = !WARM || h == 0;              // (while WARM nothing leaves: the upper half feeds zeros)
         const int sg = live ? sgn : 0;
+        const i32 llk = LLs;                            // LL of row yk (this lane half's share)
 
         // B operand: 16 bytes of the left row from the pixel's window start, bytes >= N zero
-        v4i bop;
-        {
+        v4i bop = {0, 0, 0, 0};
+        if (FEED) {
             u32 t[5], v[4];
 #pragma unroll
             for (int k = 0; k < 5; k++) t[k] = rowL[k];
@@ -123,50 +137,33 @@ __global__ __launch_bounds__(64, 2) void k_ssd_mfma(const u8 *__restrict__ left,
             }
         }
 
-        // (the right row's dwords are requested PF blocks ahead: between the scheduling barriers that keep the
-        // register count down nothing else hides the LDS latency)
+        // (the right row's dwords are requested PF blocks ahead, the table entries one block ahead: between the
+        // scheduling barriers that keep the register count down nothing else hides the LDS latency)
         constexpr int PF = 2;
         u32 tq[PF + 1][5];
+        v4i eq[2][4];
+        if (FEED) {
 #pragma unroll
-        for (int b = 0; b < PF && b < NB; b++)
+            for (int b = 0; b < PF && b < NB; b++)
 #pragma unroll
-            for (int k = 0; k < 5; k++) tq[b][k] = rowR[8 * b + k];
+                for (int k = 0; k < 5; k++) tq[b][k] = rowR[8 * b + k];
+        }
+        if (KEYS) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) eq[0][q] = *reinterpret_cast<const v4i *>(sT + 8 * q + 4 * h);
+        }
+        i32 run0 = NONE, run1 = NONE;                   // positions 0..255 (blocks 0..7) and 256.. (block 8)
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            // A operand: 16 bytes of the right row from position 32 b + xl's window start
-            if (b + PF < NB) {
+            if (FEED && b + PF < NB) {
 #pragma unroll
                 for (int k = 0; k < 5; k++) tq[(b + PF) % (PF + 1)][k] = rowR[8 * (b + PF) + k];
             }
-            const u32 *t = tq[b % (PF + 1)];
-            v4i aop;
+            if (KEYS && b + 1 < NB) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) aop[k] = (int)__builtin_amdgcn_alignbyte(t[k + 1], t[k], rho);
-            acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop, bop, acc[b], 0, 0, 0);
-            // T(u) += the entering row's squares; -= the leaving row's squares + 2 x its sum (the drift of the LR sums:
-            // the complemented left operand leaves -sum R behind in every accumulator of position u)
-            u32 s = 0;
-#pragma unroll
-            for (int k = 0; k <= FD; k++) {
-                const u32 q = k == FD ? (u32)aop[k] & MASKR : (u32)aop[k];
-                s = sdot4(q, q, s);
-                s = sdot4(q, c2, s);
+                for (int q = 0; q < 4; q++) eq[(b + 1) & 1][q] = *reinterpret_cast<const v4i *>(sT + 32 * (b + 1) + 8 * q + 4 * h);
             }
-            __hip_atomic_fetch_add(&sT[32 * b + xl], (u32)__mul24((int)s, sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_sched_barrier(0);          // (block by block: the scheduler otherwise keeps every block's operands alive)
-        }
-
-        if (OUT) {
-            i32 run0 = NONE, run1 = NONE;               // positions 0..255 (blocks 0..7) and 256.. (block 8)
-            v4i eq[2][4];                               // the table entries of a block, requested one block ahead
-#pragma unroll
-            for (int q = 0; q < 4; q++) eq[0][q] = *reinterpret_cast<const v4i *>(sT + 8 * q + 4 * h);
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                if (b + 1 < NB) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) eq[(b + 1) & 1][q] = *reinterpret_cast<const v4i *>(sT + 32 * (b + 1) + 8 * q + 4 * h);
-                }
+            if (KEYS) {
                 i32 keys[16];
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -197,8 +194,29 @@ __global__ __launch_bounds__(64, 2) void k_ssd_mfma(const u8 *__restrict__ left,
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) run = max(max(run, keys[r]), keys[r + 1]);
                 asm volatile("" : "+v"(run));            // (the maxima are otherwise deferred to the row's end, every key alive)
-                __builtin_amdgcn_sched_barrier(0);
             }
+            if (FEED) {
+                // A operand: 16 bytes of the right row from position 32 b + xl's window start
+                const u32 *t = tq[b % (PF + 1)];
+                v4i aop;
+#pragma unroll
+                for (int k = 0; k < 4; k++) aop[k] = (int)__builtin_amdgcn_alignbyte(t[k + 1], t[k], rho);
+                acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop, bop, acc[b], 0, 0, 0);
+                // T(u) += the entering row's squares; -= the leaving row's squares + 2 x its sum (the drift of the LR sums:
+                // the complemented left operand leaves -sum R behind in every accumulator of position u)
+                u32 s = 0;
+#pragma unroll
+                for (int k = 0; k <= FD; k++) {
+                    const u32 q = k == FD ? (u32)aop[k] & MASKR : (u32)aop[k];
+                    s = sdot4(q, q, s);
+                    s = sdot4(q, c2, s);
+                }
+                __hip_atomic_fetch_add(&sT[32 * b + xl], (u32)__mul24((int)s, sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // (block by block: the scheduler otherwise keeps every block's operands alive)
+        }
+
+        if (KEYS) {
             // back to keys: (RR - 2 LR) << 8 | position & 255; the first position wins among equals
             i32 k0 = -run0, v = k0 >> 8, d = (k0 & 255) - xl;
             if (NB > 8) {
@@ -208,10 +226,10 @@ __global__ __launch_bounds__(64, 2) void k_ssd_mfma(const u8 *__restrict__ left,
             // the other half of the wave holds the other positions of the same pixel
             const i32 vo = __shfl_xor(v, 32), dd = __shfl_xor(d, 32);
             if (vo < v || (vo == v && dd < d)) { v = vo; d = dd; }
-            const i32 ll = best ? LLs + __shfl_xor(LLs, 32) : 0;
+            const i32 ll = best ? llk + __shfl_xor(llk, 32) : 0;
             const int x = xw + xl;
             if (h == 0 && x < g.w && !(g.ghost && x < HALF)) {
-                const size_t o = ((size_t)pair * g.h + y) * g.w + x;
+                const size_t o = ((size_t)pair * g.h + yk) * g.w + x;
                 web[o] = d + 1;
                 if (best) best[o] = v + ll;
             }
@@ -223,10 +241,10 @@ __global__ __launch_bounds__(64, 2) void k_ssd_mfma(const u8 *__restrict__ left,
     using F = std::false_type;
     // staged row e is image row ty0 - HALF + e: output row t has window rows t .. t + N - 1
 #pragma unroll 1
-    for (int e = 0; e < N - 1; e++) step(T{}, F{}, e, 0, 0);
-    step(T{}, T{}, N - 1, 0, ty0);
+    for (int e = 0; e < N; e++) step(F{}, T{}, T{}, e, 0, 0);
 #pragma unroll 1
-    for (int t = 1; t < rows_out; t++) step(F{}, T{}, t + N - 1, t - 1, ty0 + t);
+    for (int t = 1; t < rows_out; t++) step(T{}, T{}, F{}, t + N - 1, t - 1, ty0 + t - 1);
+    step(T{}, F{}, F{}, 0, 0, ty0 + rows_out - 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -268,11 +286,12 @@ const void *sm_ssd_mfma_configure(const sm_plan *plan, int pairs, const void *d_
     g.rrow = 8 * ((g.padl + 32 * nb + 24 + 7) / 8);
     // the table: 32 nb entries, 16-byte aligned behind the staged rows
     const int tbl_bytes = 4 * 32 * nb + 16;
-    const int slots = 256 * 4 * 2;
+    const int waves = mfma_waves(nb);
+    const int slots = 256 * 4 * waves;
     int best_th = 0; double best_cost = 0;
     for (int th = 8; th <= 128; th += 4) {
         const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + tbl_bytes;
-        if (lds > 160 * 1024 / 8) break;
+        if (lds > (size_t)(160 * 1024 / (4 * waves))) break;
         const long long tiles = (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs;
         const long long rounds = (tiles + slots - 1) / slots;
         const double cost = (double)rounds * (th + 0.6 * (n - 1) + 2.0);

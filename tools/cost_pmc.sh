@@ -8,7 +8,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 tools/cost_launch.py $CFG $COST --launches 20 "$@" > "$OUT/kt.log" 2>&1 || echo "kernel-trace run failed"
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
+           "SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $set | cut -d" " -f1)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/pmc_$n" -- python3 tools/cost_launch.py $CFG $COST --launches 5 "$@" > "$OUT/pmc_$n.log" 2>&1 || echo "pmc pass $n failed"
 done
@@ -23,7 +23,7 @@ for f in glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True):
 cnt = collections.defaultdict(list)
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "k_sad" in row["Kernel_Name"] or "k_ssd" in row["Kernel_Name"] or ("k_cost" in row["Kernel_Name"] and "strip" not in row["Kernel_Name"]):
+        if "k_sad" in row["Kernel_Name"] or "k_ssd" in row["Kernel_Name"] or "k_cost" in row["Kernel_Name"]:
             cnt[(row["Kernel_Name"][:40], row["Counter_Name"])].append(float(row["Counter_Value"]))
 res["counters_per_launch"] = {f"{k[0]}|{k[1]}": sum(v) / len(v) for k, v in sorted(cnt.items())}
 json.dump(res, open(out + "/summary.json", "w"), indent=1)

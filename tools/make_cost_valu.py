@@ -18,6 +18,7 @@ for f in sorted(src.glob("cost_*_C*.json")):
     d = json.loads(f.read_text())
     w, h, shifts, _, _ = CONFIGS[cfg]
     valu = sum(v for k, v in d["counters_per_launch"].items() if k.endswith("|SQ_INSTS_VALU"))
+    mfma = sum(v for k, v in d["counters_per_launch"].items() if k.endswith("|SQ_INSTS_VALU_MFMA_I8"))
     names = [re.sub(r"^void ", "", k["Name"]).split("(")[0] for k in d["kernel_stats"]]
     out[f"{cfg}:{cost}"] = {
         "kernel": names[0] + (f" + ghost strip {names[1].split('<')[0]}" if len(names) > 1 else ""),
@@ -26,6 +27,8 @@ for f in sorted(src.glob("cost_*_C*.json")):
         "lane_instructions_per_pixel_shift": round(valu * 64 / (float(w) * h * shifts), 2),
         "source": f"{f.relative_to(ROOT) if f.is_absolute() else f} (rocprofv3 --pmc SQ_INSTS_VALU, separate passes)",
     }
+    if mfma:            # v_mfma_i32_32x32x32_i8: 2 x 32 x 32 x 32 operations each
+        out[f"{cfg}:{cost}"]["mfma_i8_instructions"] = int(round(mfma))
 order = ["C3:sad", "C5:sad", "C3:ssd", "C5:ssd"]
 out = {k: out[k] for k in order if k in out} | {k: v for k, v in out.items() if k not in order}
 (ROOT / "profiles" / "cost_valu.json").write_text(json.dumps(out, indent=1) + "\n")
