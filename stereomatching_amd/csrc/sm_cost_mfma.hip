@@ -41,6 +41,9 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ u32 sdot4(u32 a, u32 b, u32 acc) { return (u32)__builtin_amdgcn_sdot4((int)a, (int)b, (int)acc, false); }
 
+#ifndef MFMA_EXP
+#define MFMA_EXP 0      // (timing experiments only, results wrong: 1 no table reads, 2 no table update, 3 no MFMA, 4 no keys)
+#endif
 // waves per SIMD the register count allows: the NB x 16 accumulators are most of it
 #ifndef MFMA_W3
 #define MFMA_W3 5
@@ -159,11 +162,13 @@ __global__ __launch_bounds__(64, mfma_waves(NB)) void k_ssd_mfma(const u8 *__res
 #pragma unroll
                 for (int k = 0; k < 5; k++) tq[(b + PF) % (PF + 1)][k] = rowR[8 * (b + PF) + k];
             }
+#if MFMA_EXP != 1
             if (KEYS && b + 1 < NB) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) eq[(b + 1) & 1][q] = *reinterpret_cast<const v4i *>(sT + 32 * (b + 1) + 8 * q + 4 * h);
             }
-            if (KEYS) {
+#endif
+            if (KEYS && MFMA_EXP != 4) {
                 i32 keys[16];
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -201,9 +206,14 @@ __global__ __launch_bounds__(64, mfma_waves(NB)) void k_ssd_mfma(const u8 *__res
                 v4i aop;
 #pragma unroll
                 for (int k = 0; k < 4; k++) aop[k] = (int)__builtin_amdgcn_alignbyte(t[k + 1], t[k], rho);
+#if MFMA_EXP != 3
                 acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop, bop, acc[b], 0, 0, 0);
+#else
+                acc[b][0] += aop[0] ^ bop[0]; acc[b][5] += aop[1] ^ bop[1]; acc[b][10] += aop[2] ^ bop[2]; acc[b][15] += aop[3] ^ bop[3];
+#endif
                 // T(u) += the entering row's squares; -= the leaving row's squares + 2 x its sum (the drift of the LR sums:
                 // the complemented left operand leaves -sum R behind in every accumulator of position u)
+#if MFMA_EXP != 2
                 u32 s = 0;
 #pragma unroll
                 for (int k = 0; k <= FD; k++) {
@@ -212,6 +222,7 @@ __global__ __launch_bounds__(64, mfma_waves(NB)) void k_ssd_mfma(const u8 *__res
                     s = sdot4(q, c2, s);
                 }
                 __hip_atomic_fetch_add(&sT[32 * b + xl], (u32)__mul24((int)s, sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);          // (block by block: the scheduler otherwise keeps every block's operands alive)
         }
