@@ -16,8 +16,8 @@ struct SadGeom {
     int q_tail;              // first quad of a lane that may hold shifts >= D
     int q_last;              // last quad in which some lane has a shift < D
     int fast_stage;          // image rows are dword-aligned and w % 4 == 0
-    int rr_stride;           // SSD: dwords between the four residue classes of the RR table (sm_cost_ssd.hip);
-                             // sm_cost_mfma.hip: dwords of padding in front of its table
+    int rr_stride;           // k_ssd_dot: dwords between the four residue classes of its RR table
+    int tbl_pad;             // k_ssd_mfma: dwords between the staged rows and its (16-byte aligned) RR table
     int lds_bytes;
 };
 

@@ -23,9 +23,10 @@
 // A lane holds ONE pixel (x = lane % 32) and 16 right positions per block: the arg-min over the shifts is
 // in-register, 1.5 instructions per (pixel, shift) -- v_lshl_add_u32 forms -key = (LR << 9) + entry(u),
 // entry(u) = -(RR(u) << 8) - (u & 255) read as one ds_read_b128 per four positions, and one v_max3_i32 takes
-// two keys -- then one exchange between the lane halves.  The dot-product kernel (sm_cost_ssd.hip) needs
-// 10 instructions per (pixel, shift) for the same result; this one ~3.4 (RR table and operand set-up
-// included), and the matrix pipe is busy for 9 x 32 cycles of a row's ~1 500.
+// two keys -- then one exchange between the lane halves.  Measured at C5 (4K, 256 shifts, 11 x 11): 4.06
+// VALU lane-instructions per (pixel, shift), RR table and operand set-up included, against 14.5 for the
+// dot-product kernel (sm_cost_ssd.hip); 403 us per launch against 974; the matrix pipe is busy 11 % of
+// the time (profiles/r04/cost_ssd_C5.json).
 //
 // Ghost border: as in the other two kernels, rows / columns outside the image are staged as zero pixels in
 // both images; the columns x < half are recomputed by the masked kernel of sm_cost.hip.
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64, mfma_waves(NB)) void k_ssd_mfma(const u8 *__res
     u32 *sL = lds;                                                   // [nsr][lw]
     u32 *sR = sL + g.nsr * lw;                                       // [nsr][rw]
     // entry(u) = -(T(u) << 8) - (u & 255), T = RR minus twice the drift of the LR sums (see the step); 16-byte aligned
-    u32 *sT = sR + g.nsr * rw + g.rr_stride;
+    u32 *sT = sR + g.nsr * rw + g.tbl_pad;
 
     smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid, 0x80808080u);   // signed bytes: pixel - 128
     for (int u = tid; u < 32 * NB; u += 64) sT[u] = (u32)(-(u & 255));
@@ -319,7 +320,8 @@ const void *sm_ssd_mfma_configure(const sm_plan *plan, int pairs, const void *d_
     g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0 &&
                    g.lrow + g.rrow <= 4 * 256;
     // dwords between the end of the staged rows and the table: whatever makes the table 16-byte aligned
-    g.rr_stride = (4 - (g.nsr * ((g.lrow + g.rrow) >> 2)) % 4) % 4;
+    g.rr_stride = 0;
+    g.tbl_pad = (4 - (g.nsr * ((g.lrow + g.rrow) >> 2)) % 4) % 4;
     g.lds_bytes = g.nsr * (g.lrow + g.rrow) + tbl_bytes;
     const void *fn = nullptr;
     switch (n) {

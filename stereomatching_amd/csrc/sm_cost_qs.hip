@@ -326,7 +326,7 @@ static const void *sad_qs2_ptr(int nql, int px)
 const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *out)
 {
     SadGeom g;
-    g.rr_stride = 0;        // (the SSD kernel's)
+    g.rr_stride = 0; g.tbl_pad = 0;         // (the SSD kernels')
     g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
     const int half = plan->square_width / 2, n = 2 * half + 1;
     g.ghost = plan->border == SM_GHOST;

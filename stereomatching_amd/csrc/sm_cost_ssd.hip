@@ -363,6 +363,7 @@ const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_l
     g.rrow = 8 * ((g.padl + g.tw + 4 * (g.nl * nql + ng + 3) + 7) / 8);
     g.q_tail = g.D - 4 * nql * (g.nl - 1);          // shifts of the last shift-lane below D
     g.q_last = nql - 1;
+    g.tbl_pad = 0;
     g.rr_stride = g.rrow / 4 + 1;
     while (g.rr_stride % 8 != 5) g.rr_stride++;
     const size_t rr_bytes = 16 * (size_t)g.rr_stride;
