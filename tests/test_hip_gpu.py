@@ -897,6 +897,53 @@ def test_cost_kernels_random_shapes_match_own_oracle(hip):
         print(f"cost soak: {soak} cases, all equal to the build's own CPU definition")
 
 
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+def test_ssd_matrix_core_kernel_every_instantiation(hip, mode):
+    """k_ssd_mfma<N, NB>: every window 3 .. 11 x every block count 1 .. 9, with the shift counts either side of
+    each block boundary (the band's partial blocks: D a multiple of 32 takes the complementary-triangle masks,
+    anything else the per-key compares on the last two blocks), web and best, against the CPU definition and the
+    byte-dot kernel; ghost mode adds k_cost_strip<half, SSD> behind it."""
+    rng = np.random.default_rng(41)
+    for sw in (3, 5, 7, 9, 11):
+        for d in (1, 2, 31, 32, 33, 34, 64, 65, 95, 96, 97, 128, 129, 160, 161, 191, 192, 193, 224, 225, 255, 256):
+            w, h = 76, sw + 5
+            left = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            right = np.roll(left, int(rng.integers(0, min(d, w))), 1)
+            right = np.clip(right.astype(np.int32) + rng.integers(-2, 3, (h, w)), 0, 255).astype(np.uint8)
+            if d % 3 == 0:
+                left[::2, ::7] = 0; right[1::3, ::5] = 255
+            plan = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_tile_h=3 if d % 2 else 0))
+            web, best = plan.cost_wta(dev(left), dev(right), "ssd")
+            ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, "ssd")
+            assert np.array_equal(host(web)[0], ow), (mode, sw, d)
+            assert np.array_equal(host(best)[0], ob), (mode, sw, d)
+            plan.close()
+
+
+@pytest.mark.parametrize("cost", ["sad", "ssd"])
+def test_ghost_strip_kernel_every_instantiation(hip, cost):
+    """k_cost_strip<half, SSD, slots>: every half-window 1 .. 10 (SSD: .. 5), one and two shifts per thread,
+    images no wider than the window, heights around its tile boundaries, against the CPU definition and the
+    general masked kernel on the same columns (cost_kernel = 3)"""
+    rng = np.random.default_rng(43)
+    for half in range(1, 11 if cost == "sad" else 6):
+        sw = 2 * half + 1
+        for d, w, h in ((40, 64, sw + 9), (300, 48, sw + 2), (200, sw, 37), (256, 96, 70)):
+            if cost == "sad" and sw > 15 and d > 240:
+                d = 240                 # (the split-accumulator SAD kernel's shift field)
+            left = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            right = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            plan = hip.StereoPlan(w, h, d, sw, "ghost")
+            web, best = plan.cost_wta(dev(left), dev(right), cost)
+            ob, ow = oracle.cost_hot_path(left, right, d, sw, "ghost", cost)
+            assert np.array_equal(host(web)[0], ow), (cost, half, d, w, h)
+            assert np.array_equal(host(best)[0], ob), (cost, half, d, w, h)
+            old = hip.StereoPlan(w, h, d, sw, "ghost", options=dict(cost_kernel=3))
+            web2, best2 = old.cost_wta(dev(left), dev(right), cost)
+            assert torch.equal(web2, web) and torch.equal(best2, best)
+            plan.close(); old.close()
+
+
 @pytest.mark.parametrize("cfg,cost", [("C3", "sad"), ("C5", "sad"), ("C3", "ssd"), ("C5", "ssd")])
 def test_cost_mode_4k_full_image_vs_own_oracle(hip, cfg, cost):
     """The 4K configurations in the SAD / SSD cost mode (PARITY UNPINNED: the build's own CPU
