@@ -32,9 +32,9 @@
 //
 // Ghost border: rows / columns outside the image are staged as zeros in both images, which gives
 // the oracle's "no tap outside the image, zeros past the right border" -- except for taps LEFT of
-// the image (left = 0, right(x' + d) inside).  The columns x < half are therefore recomputed
-// by the masked kernel of sm_cost.hip (launch_general with strip_cols), a launch of a few hundred short
-// workgroups behind this one (beside it, on a stream of its own, it costs more than it takes: sm_cost_wta).
+// the image (left = 0, right(x' + d) inside).  The columns x < half are therefore recomputed by
+// sm_cost_strip.hip, a short launch behind this one (beside it, on a stream of its own, it costs more than it
+// takes: sm_cost_wta).
 //
 // SPLIT (n = 17, 19, 21): a window sum reaches 21 * 21 * 255 = 112 455, more than 16 bits.  The window's
 // column groups are split between two packed accumulators -- the first three groups (12 columns: at most

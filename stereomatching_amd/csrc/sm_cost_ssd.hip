@@ -1,14 +1,20 @@
-// sm_cost_ssd.hip -- SSD cost mode of the hot path on the byte dot-product unit.
+// sm_cost_ssd.hip -- SSD cost mode of the hot path on the byte dot-product unit (rounds 2-4).  Since round 4 the
+// plan takes the matrix-core kernel (sm_cost_mfma.hip) where both apply; this one is sm_plan_options.cost_kernel = 2
+// and the second implementation the tests compare that one with.
 //
 // PARITY UNPINNED: the reference has no SSD implementation; the mode is
 // the build's own definition (stated at the top of sm_cost.hip; the checker restates it on the CPU).
 //
 //   SSD_d(x, y) = sum over the n x n window of (L - R)^2 = LL(x, y) + RR(x + d, y) - 2 LR_d(x, y)
 // with LL / RR the window sums of the squared left / right pixels -- one value per PIXEL and row,
-// not per shift -- and LR_d the window sum of the products, the only per-shift work:
-//     t  = dot4(left group, right group of the row that slides out, ...)       NG = ceil(n/4) x v_dot4_u32_u8
-//     LR = dot4(left group, right group of the row that slides in, LR) - t     NG + 1
-//     -key = (LR << 9) - (RR[x + d] << 8) - shift    key = (RR - 2 LR) << 8 | shift: signed, first shift wins
+// not per shift -- and LR_d the window sum of the products, the only per-shift work.  Pixels are staged as
+// SIGNED bytes, pixel - 128 (differences do not care), and the row that slides out is read COMPLEMENTED on
+// the right side: ~r = -r - 1, so its v_dot4 takes the products off the same accumulator (plus the old row's
+// left pixels once each: a drift that is the same for every shift of a pixel, cannot change the arg-min and
+// comes off `best` with LL):
+//     LR = dot4(left group, ~right group of the row that slides out, LR)       NG = ceil(n/4) x v_dot4c_i32_i8
+//     LR = dot4(left group, right group of the row that slides in, LR)         NG
+//     -key = (LR << 9) + entry                         entry = -(RR[x + d] << 8) - offset of the entry in the lane's span
 //     best = max3(best, -key of an even quad, -key of the odd quad behind it)
 // The last group of a window row holds n mod 4 pixels: the other bytes of the LEFT operand are
 // zeroed and their products vanish -- no correction term (as the SAD kernel needs) exists here.
@@ -16,12 +22,12 @@
 // A lane owns PX pixels (4 apart) x 32 shifts; the right operand of shift d is the right row's dword
 // at byte x - half + d + 4 g: the row is re-based to the lane's window start once, then its four byte
 // alignments are cut with v_alignbyte once per row and shared by the lane's pixels and the eight shifts
-// of that alignment.  RR is a
-// table in LDS over the right-image positions of the tile, slid down row by row by the wave.
+// of that alignment.  RR is a table in LDS over the right-image positions of the tile, split by residue
+// (see below), slid down row by row by the wave.
 //
-// Ghost border: as in the SAD kernel, rows / columns outside the image are staged as zeros in both
+// Ghost border: as in the SAD kernel, rows / columns outside the image are staged as zero pixels in both
 // images; the columns x < half (taps left of the image, where the right image is not zero) are
-// recomputed by the masked kernel of sm_cost.hip.
+// recomputed by sm_cost_strip.hip behind this launch.
 //
 // Limits: windows up to 11 x 11 (RR - 2 LR = SSD - LL lies in (-2^23, 2^23): 24 signed bits of the key)
 // and 256 shifts (the other 8).
@@ -30,15 +36,8 @@
 #include "sm_cost.h"
 #include <type_traits>
 
-#ifndef SSD_SIGNED
-#define SSD_SIGNED 1
-#endif
-#if SSD_SIGNED
 // signed bytes (pixel - 128, staged that way): v_dot4c_i32_i8
 __device__ __forceinline__ u32 dot4(u32 a, u32 b, u32 acc) { return (u32)__builtin_amdgcn_sdot4((int)a, (int)b, (int)acc, false); }
-#else
-__device__ __forceinline__ u32 dot4(u32 a, u32 b, u32 acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
-#endif
 
 template <int N, int PX, bool FULLD>
 __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, const u8 *__restrict__ right,
@@ -74,7 +73,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
     u32 *sRR = sR + g.nsr * rw;                                      // [4][rr_stride]
     const int S = g.rr_stride;
 
-    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid, SSD_SIGNED ? 0x80808080u : 0u);
+    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid, 0x80808080u);
     for (int r = tid; r < 4 * S; r += 64) sRR[r] = 0;
     __syncthreads();
 
@@ -171,9 +170,7 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                 if (!WARM) {
                     const u32 u = gp == FG ? uop[p] : uo[p + gp];
                     so = dot4(u, u, so);
-#if SSD_SIGNED
                     so = dot4(u, 0x02020202u, so);      // + 2 x the old row's sum: the drift C of the LR sums, see below
-#endif
                 }
             }
             LLs[p] += sn - so;
@@ -199,13 +196,11 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
             if (!WARM) {
 #pragma unroll
                 for (int k = 0; k < K + 2; k++) t[k] = rowRo[bR + k];
-#if SSD_SIGNED
                 // the old row's right operand COMPLEMENTED: as signed bytes ~r = -r - 1, so its v_dot4 SUBTRACTS the old
                 // row's products (and the old row's left pixels once each, a drift C that is the same for every
                 // shift of a pixel -- it cannot change the arg-min and comes off `best` through LLs)
 #pragma unroll
                 for (int k = 0; k < K + 2; k++) t[k] = ~t[k];
-#endif
 #pragma unroll
                 for (int k = 0; k <= K; k++) wo[k] = __builtin_amdgcn_alignbyte(t[k + 1], t[k], rho);
             }
@@ -240,7 +235,6 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                 u32 acc[PX];
 #pragma unroll
                 for (int p = 0; p < PX; p++) acc[p] = A[p][m][i];
-#if SSD_SIGNED
                 // one chain per pixel: the old row's groups against the complemented right row take their products off
                 if (!WARM) {
 #pragma unroll
@@ -254,23 +248,6 @@ __global__ __launch_bounds__(64, 2) void k_ssd_dot(const u8 *__restrict__ left, 
                     for (int p = 0; p < PX; p++) acc[p] = dot4(gp == FG ? unp[p] : un[p + gp], rn[p + m + gp], acc[p]);
 #pragma unroll
                 for (int p = 0; p < PX; p++) A[p][m][i] = acc[p];
-#else
-                u32 t[PX];
-#pragma unroll
-                for (int p = 0; p < PX; p++) t[p] = 0;
-                if (!WARM) {
-#pragma unroll
-                    for (int gp = 0; gp < NG; gp++)
-#pragma unroll
-                        for (int p = 0; p < PX; p++) t[p] = dot4(gp == FG ? uop[p] : uo[p + gp], ro[p + m + gp], t[p]);
-                }
-#pragma unroll
-                for (int gp = 0; gp < NG; gp++)
-#pragma unroll
-                    for (int p = 0; p < PX; p++) acc[p] = dot4(gp == FG ? unp[p] : un[p + gp], rn[p + m + gp], acc[p]);
-#pragma unroll
-                for (int p = 0; p < PX; p++) { acc[p] -= t[p]; A[p][m][i] = acc[p]; }
-#endif
                 if (OUT) {
                     // key = (RR - 2 LR) << 8 | shift within the lane, signed: the smallest wins, i.e. the lowest
                     // SSD (LL is the same for all shifts of a pixel) and among equals the first shift.  Formed
