@@ -292,10 +292,12 @@ int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gra
  * sum, best = min over d, web = 1 + the FIRST d reaching it; borders as the
  * reference treats its edge images (wrap, or zeros past the border and no taps
  * outside the image).  Defined by oracle/stereo_oracle.c smo_cost_hot_path.
- * Windows up to 25 x 25, num_shifts <= 512.  SAD windows 3 .. 15 run on the
- * quad-SAD unit, SSD windows 3 .. 11 with up to 256 shifts on the byte
- * dot-product unit; everything else on a general kernel --
- * the same results by definition (tests: both paths against the definition). */
+ * Windows up to 25 x 25, num_shifts <= 512.  SAD windows 3 .. 21 run on the
+ * quad-SAD unit, SSD windows 3 .. 11 with up to 256 shifts on the matrix cores
+ * (or, sm_plan_options.cost_kernel = 2, on the byte dot-product unit), the
+ * ghost border's columns x < half behind them on a kernel of their own
+ * (DESIGN.md 5.4); everything else on a general kernel -- the same results by
+ * definition (tests: every path against the definition).                     */
 #define SM_COST_SAD 1
 #define SM_COST_SSD 2
 int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
