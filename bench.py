@@ -213,7 +213,7 @@ def cpu_baseline(w, d, sw, mode, rows, threshold):
 
 
 def cost_modes(dev):
-    """The extra `sad` / `ssd` objects: the SAD / SSD cost mode (sm_cost_wta) at the two BASELINE
+    """The extra `sad` / `ssd` (and `ssd_c3`: SSD on the headline geometry) objects: the SAD / SSD cost mode (sm_cost_wta) at the two BASELINE
     configurations that word their cost that way.  PARITY UNPINNED -- the reference implements the
     edge-equality cost and nothing else -- so these are reported beside the
     headline, never in it."""
@@ -227,7 +227,7 @@ def cost_modes(dev):
     if cfile.exists():
         counts = json.loads(cfile.read_text())
     res = {}
-    for key, cfg, cost in (("sad", "C3", "sad"), ("ssd", "C5", "ssd")):
+    for key, cfg, cost in (("sad", "C3", "sad"), ("ssd", "C5", "ssd"), ("ssd_c3", "C3", "ssd")):
         w, h, d, sw, mode = CONFIGS[cfg]
         plan = pipeline.StereoPlan(w, h, d, sw, mode, device=dev.index)
         ls, rs = zip(*[make_pair(w, h, d, seed=500 + j) for j in range(2)])

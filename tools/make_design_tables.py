@@ -127,7 +127,7 @@ if d:
         c = d["cpu_baseline"]
         ex.append(f"CPU baseline ({c['kind']}, {c['cores']} core): {c['value']} {c['unit']}" +
                   (f"; {c['all_cores']['value']} on {c['all_cores']['cores']} threads" if "all_cores" in c else ""))
-    for k in ("sad", "ssd"):
+    for k in ("sad", "ssd", "ssd_c3"):
         if k in d:
             o = d[k]
             ex.append(f"`{k}` ({o['workload'].split(':')[0]}, parity unpinned): {o['ms_per_launch']} ms per launch, "
