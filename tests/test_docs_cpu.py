@@ -43,3 +43,18 @@ def test_trace_and_line_agree():
     # ... and the roofline's traffic is the compulsory bytes (no wasted re-reads or double writes)
     t = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())["C3:1"]
     assert t["source"].endswith("r04") and 35.0e6 < t["bytes_per_launch"] < 37.0e6
+
+
+def test_cost_profile_names_kernels_that_exist():
+    """profiles/cost_valu.json (what bench.py prices its `sad` / `ssd` objects with) names kernels the sources
+    define, and DESIGN.md's abbreviated profile citations (`ab_*.txt` without a directory) point at files under
+    profiles/r04/"""
+    src = "".join(p.read_text() for p in (ROOT / "stereomatching_amd" / "csrc").glob("*.hip"))
+    for key, c in json.loads((ROOT / "profiles" / "cost_valu.json").read_text()).items():
+        for name in re.findall(r"k_[a-z_0-9]+", c["kernel"]):
+            assert f"void {name}(" in src, (key, name)
+        assert (ROOT / c["source"].split(" ")[0]).exists(), c["source"]
+    text = (ROOT / "DESIGN.md").read_text()
+    missing = [f for f in set(re.findall(r"`(?:…/)?((?:ab|pmc|ds_choice|write_size|cost)_[A-Za-z0-9_]+\.(?:txt|json))`", text))
+               if not (ROOT / "profiles" / "r04" / f).exists() and not (ROOT / "profiles" / "r03" / f).exists()]
+    assert not missing, missing
