@@ -26,7 +26,7 @@ CFLAGS := -std=gnu11 -Wall -Wextra -pedantic -Wno-unused-parameter -Iinclude -Io
 
 HOSTDIR := stereomatching_amd/host
 CSRC    := stereomatching_amd/csrc
-KERNELS := sm_match_bs_ds8 sm_match_bs sm_match_bs_duo8 sm_match_bs_duo sm_match_bs_ds4 sm_api sm_match sm_cost sm_cost_qs sm_cost_ssd sm_cost_mfma sm_cost_strip sm_gather
+KERNELS := sm_match_bs_ds8 sm_match_bs sm_match_bs_duo8 sm_match_bs_duo sm_match_bs_ds4 sm_api sm_match sm_cost sm_cost_qs sm_cost_pc sm_cost_ssd sm_cost_mfma sm_cost_strip sm_gather
 DEVOBJ  := $(addprefix stereomatching_amd/obj/product/,$(addsuffix .o,$(KERNELS)))
 # (the same flags, in the same order, as HIPCC_FLAGS of stereomatching_amd/build.py: the two share
 #  stereomatching_amd/obj/product and its flags.txt stamp, so neither rebuilds what the other built)

@@ -142,7 +142,9 @@ typedef struct sm_plan_options {
     int cost_tile_h;            /* SAD / SSD kernels: output rows per wave */
     int cost_kernel;            /* 1 = the general masked kernel even where the quad-SAD / MFMA / dot kernels apply;
                                    2 = SSD on the byte dot-product unit instead of the matrix cores;
-                                   3 = the ghost-border strip by the general masked kernel (as until round 3) */
+                                   3 = the ghost-border strip by the general masked kernel (as until round 3);
+                                   4 = SAD by the round-4 kernel (every window row from scratch) where the
+                                       prefix-chain kernel of round 5 applies */
     int priority_class;         /* bit-sliced kernel: which of a SIMD's two waves a priority slice favours is told by
                                  * 1 = the wave slot's parity, 2 = the parity of the workgroup's slot on its CU (the two
                                  * waves of a two-wave workgroup are then favoured together); 0 = the plan's choice */

@@ -20,7 +20,7 @@ LIB = PKG / "libstereo_hip.so"
 # the bit-sliced kernel's builds are spread over four translation units so that they
 # compile side by side (one unit: ~2 min; four beside the rest: ~50 s on 8 cores)
 SOURCES = ["sm_match_bs_ds8.hip", "sm_match_bs.hip", "sm_match_bs_duo8.hip", "sm_match_bs_duo.hip", "sm_match_bs_ds4.hip",
-           "sm_api.hip", "sm_match.hip", "sm_cost.hip", "sm_cost_qs.hip", "sm_cost_ssd.hip", "sm_cost_mfma.hip", "sm_cost_strip.hip", "sm_gather.hip"]
+           "sm_api.hip", "sm_match.hip", "sm_cost.hip", "sm_cost_qs.hip", "sm_cost_pc.hip", "sm_cost_ssd.hip", "sm_cost_mfma.hip", "sm_cost_strip.hip", "sm_gather.hip"]
 HEADERS = [CSRC / "sm_internal.h", CSRC / "sm_match_bs_kernel.h", CSRC / "sm_cost.h", ROOT / "include" / "stereo_hip.h"]
 OBJDIR = PKG / "obj"
 HIPCC_FLAGS = [

@@ -99,8 +99,10 @@ __device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ 
 }
 #endif
 
-// sm_cost_qs.hip / sm_cost_ssd.hip / sm_cost_mfma.hip: fill *g and return the kernel for this plan, or nullptr if the shape is not built
+// sm_cost_qs.hip / sm_cost_pc.hip / sm_cost_ssd.hip / sm_cost_mfma.hip: fill *g and return the kernel for this plan, or nullptr if the shape is not built
 const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
+// sm_cost_pc.hip: SAD with the window rows formed by prefix chains along the row (round 5; windows up to 15 x 15)
+const void *sm_sad_pc_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
 const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
 const void *sm_ssd_mfma_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *g);
 // sm_cost_strip.hip: the ghost-border columns x < half behind a fast kernel's launch; -1 if not built for this shape

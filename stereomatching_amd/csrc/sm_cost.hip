@@ -330,12 +330,14 @@ extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint
     const hipError_t es = hipSetDevice(plan->device);
     if (es != hipSuccess) return sm_fail(SM_ERR_HIP, "sm_cost_wta: %s", hipGetErrorString(es));
     {
-        // SAD on the quad-SAD unit (sm_cost_qs.hip), SSD on the matrix cores (sm_cost_mfma.hip; cost_kernel = 2: on the
+        // SAD on the quad-SAD unit (sm_cost_pc.hip: window rows by prefix chains, windows up to 15 x 15; sm_cost_qs.hip:
+        // the larger ones, and cost_kernel = 4), SSD on the matrix cores (sm_cost_mfma.hip; cost_kernel = 2: on the
         // byte dot-product unit, sm_cost_ssd.hip),
         // where they are built for this window and shift count; otherwise the general masked kernel
         SadGeom q;
-        const void *fn = cost == SM_COST_SAD ? sm_sad_qs_configure(plan, pairs, d_gray_left, d_gray_right, &q)
+        const void *fn = cost == SM_COST_SAD ? sm_sad_pc_configure(plan, pairs, d_gray_left, d_gray_right, &q)
                                              : sm_ssd_mfma_configure(plan, pairs, d_gray_left, d_gray_right, &q);
+        if (!fn && cost == SM_COST_SAD) fn = sm_sad_qs_configure(plan, pairs, d_gray_left, d_gray_right, &q);
         if (!fn && cost == SM_COST_SSD) fn = sm_ssd_dot_configure(plan, pairs, d_gray_left, d_gray_right, &q);
         if (fn) {
             void *args[] = {(void *)&d_gray_left, (void *)&d_gray_right, (void *)&d_web, (void *)&d_best, (void *)&q};

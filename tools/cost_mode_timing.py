@@ -1,5 +1,5 @@
 """SAD / SSD cost mode (parity unpinned): time per launch at the BASELINE configurations.
-    python tools/cost_mode_timing.py [C2 C3 C5 ...]"""
+    python tools/cost_mode_timing.py [C2 C3 C5 ...] [WxHxDxS[g] ...] [sad] [ssd]     (g: ghost border)"""
 import sys
 sys.path.insert(0, '.')
 import torch
@@ -7,6 +7,11 @@ from stereomatching_amd import pipeline
 from stereomatching_amd.synth import CONFIGS, make_pair
 
 from tools._options import from_env          # SM_COST_PX / SM_COST_TILE_H / SM_COST_KERNEL in this tool's environment
+import re
+for a in sys.argv[1:]:
+    m = re.fullmatch(r"(\d+)x(\d+)x(\d+)x(\d+)(g?)", a)
+    if m:
+        CONFIGS[a] = (int(m[1]), int(m[2]), int(m[3]), int(m[4]), "ghost" if m[5] else "toroidal")
 cfgs = [a for a in sys.argv[1:] if a in CONFIGS] or ["C2", "C3", "C5"]
 costs = [a for a in sys.argv[1:] if a in ("sad", "ssd")] or ["sad", "ssd"]
 for cfg in cfgs:
