@@ -157,6 +157,8 @@ typedef struct sm_plan_options {
                                  * and 4); shifts_per_lane = 4 forces them where they are built */
     int priority_unit_log2;     /* bit-sliced kernel: log2 of the priority schedule's unit in shader-clock cycles (8 .. 20;
                                  * bit k of priority_pattern covers the k-th unit); 0 = the plan's choice */
+    int cost_workgroup_waves;   /* SAD kernel of round 5 (prefix chains): 1, 2 or 4 waves per workgroup sharing the staged
+                                 * rows; 0 = the plan's choice */
 } sm_plan_options;
 int sm_plan_create_ex(int device, int width, int height, int num_shifts, int square_width,
                       int border, int max_pairs, const sm_plan_options *options, sm_plan **out);
@@ -280,6 +282,23 @@ int sm_plan_time_stride(sm_plan *plan, int every);
 int sm_run(sm_plan *plan, const uint8_t *d_gray_left,
            const uint8_t *d_gray_right, double threshold, int pairs,
            int32_t *d_web, int32_t *d_best, void *stream);
+
+/* STREAM CAPTURE (hipStreamBeginCapture on `stream`, torch.cuda.graph): sm_run, sm_find_edges, sm_match_wta and
+ * sm_cost_wta may be recorded into a graph and replayed; a plan is single-stream, so do not run it eagerly while a
+ * graph that holds its launches is in flight.  What cannot be captured returns SM_ERR_ARG with a message that names
+ * the remedy, and leaves the capture valid:
+ *   - a threshold whose decision tables are not built yet (their set-up reads a verdict back to the host):
+ *     call sm_plan_prepare_threshold before the capture begins;
+ *   - a match launch with kernel timing armed (its events cannot be read back from a graph):
+ *     sm_plan_time_kernels(plan, 0) before the capture;
+ *   - the first narrow result of a plan whose kernel needs the int32 staging map (an allocation):
+ *     sm_plan_reserve_narrow before the capture.
+ * A PIPELINED plan is captured with a protocol of its own: the lane of a call leaves `stream` at an event the
+ * previous captured call recorded before it joined its own lane back, so consecutive calls still run side by side
+ * inside the graph, every call joins at once (a capture may end after any call), and -- unlike outside a capture --
+ * every call is ordered behind the work captured on `stream` before the capture's FIRST sm_run.  (Round 4 saw a
+ * crash here: its lanes waited for release events recorded before the capture began, which the runtime answers with
+ * hipErrorStreamCaptureIsolation; tools/capture_probe.hip.)                                                        */
 
 /* sm_run with a narrow web map (see sm_match_wta_typed) */
 int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,

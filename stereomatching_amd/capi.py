@@ -53,7 +53,7 @@ class PlanOptions(C.Structure):
                 ("priority_pattern", C.c_uint), ("edge_kernel", C.c_int), ("timing_by_records", C.c_int),
                 ("cost_pixels_per_lane", C.c_int), ("cost_tile_h", C.c_int), ("cost_kernel", C.c_int),
                 ("priority_class", C.c_int), ("priority_on_change", C.c_int), ("lane_merge", C.c_int),
-                ("no_four_shift_lanes", C.c_int), ("priority_unit_log2", C.c_int)]
+                ("no_four_shift_lanes", C.c_int), ("priority_unit_log2", C.c_int), ("cost_workgroup_waves", C.c_int)]
 
     @classmethod
     def make(cls, **kw):

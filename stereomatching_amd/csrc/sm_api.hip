@@ -894,6 +894,7 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
     for (int q = 0; q < 4 && e == hipSuccess; q++) e = hipEventCreateWithFlags(&p->ev_free[q], hipEventDisableTiming);
     p->d_ext = p->d_ext_buf[0];
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_inputs, hipEventDisableTiming);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipEventCreateWithFlags(&p->ev_fork[b], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flags, 4 * sizeof(i32));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_edge_tab, 768 * sizeof(u32));
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_flags, 4 * sizeof(i32), hipHostMallocDefault);
@@ -910,6 +911,8 @@ extern "C" int sm_plan_create_ex(int device, int width, int height, int num_shif
         for (int q = 0; q < 4; q++)
             if (p->ev_free[q]) (void)hipEventDestroy(p->ev_free[q]);
         if (p->ev_inputs) (void)hipEventDestroy(p->ev_inputs);
+        for (int b = 0; b < 2; b++)
+            if (p->ev_fork[b]) (void)hipEventDestroy(p->ev_fork[b]);
         if (p->d_flags) (void)hipFree(p->d_flags);
         if (p->d_edge_tab) (void)hipFree(p->d_edge_tab);
         if (p->d_web_tmp) (void)hipFree(p->d_web_tmp);
@@ -974,6 +977,7 @@ extern "C" void sm_plan_destroy(sm_plan *plan)
     }
     for (int q = 0; q < 4; q++) (void)hipEventDestroy(plan->ev_free[q]);
     (void)hipEventDestroy(plan->ev_inputs);
+    for (int b = 0; b < 2; b++) (void)hipEventDestroy(plan->ev_fork[b]);
     if (plan->d_web_tmp) (void)hipFree(plan->d_web_tmp);
     (void)hipFree(plan->d_flags);
     (void)hipFree(plan->d_edge_tab);
@@ -1025,6 +1029,17 @@ static int read_flags(sm_plan *plan, hipStream_t st, int clear_mask, i32 out[4])
     return SM_OK;
 }
 
+// Is `st` recording into a graph (hipStreamBeginCapture, torch.cuda.graph)?  Asked only on the paths that cannot be
+// captured or need another protocol inside a capture: the steady state of a plain plan never calls it.
+static bool stream_capturing(hipStream_t st, unsigned long long *id = nullptr)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    if (hipStreamGetCaptureInfo(st, &cs, &cid) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (id) *id = cid;
+    return cs != hipStreamCaptureStatusNone;
+}
+
 static int check_plan_pairs(const sm_plan *plan, int pairs, const char *who)
 {
     if (!plan) return sm_fail(SM_ERR_ARG, "%s: plan is NULL", who);
@@ -1055,6 +1070,10 @@ static int ensure_edge_tables(sm_plan *plan, double threshold, hipStream_t st)
 {
     if (plan->tab_valid && memcmp(&plan->tab_threshold, &threshold, sizeof threshold) == 0)
         return SM_OK;
+    if (stream_capturing(st))
+        return sm_fail(SM_ERR_ARG, "the decision tables of threshold %g are not prepared and the stream is capturing: their "
+                       "set-up reads a verdict back to the host, which a graph cannot hold -- call "
+                       "sm_plan_prepare_threshold(plan, threshold, stream) before the capture begins", threshold);
     SM_HIP(hipMemsetAsync(&plan->d_flags[2], 0, sizeof(i32), st));
     hipLaunchKernelGGL(k_edge_thresholds, dim3(766), dim3(256), 0, st, threshold,
                        plan->d_edge_tab, &plan->d_flags[2]);
@@ -1194,6 +1213,9 @@ extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int
     if (via_tmp) {
         if (!plan->d_web_tmp) {         // the first narrow request on such a plan (sm_plan_reserve_narrow keeps
             SM_TRY(use_device(plan->device));      // this allocation, which synchronises the device, out of a timed path)
+            if (stream_capturing((hipStream_t)stream))
+                return sm_fail(SM_ERR_ARG, "%s: the int32 staging map of narrow results is not allocated and the stream is "
+                               "capturing (an allocation cannot be captured): call sm_plan_reserve_narrow(plan) first", me);
             SM_TRY(reserve_narrow(plan, me));
         }
         d_web = plan->d_web_tmp;
@@ -1206,6 +1228,10 @@ extern "C" int sm_match_wta_typed(sm_plan *plan, int pairs, void *d_web_any, int
     // the launches, and record the buffer-release event only when someone can wait on it
     const bool timed = plan->timing_n < plan->timing_cap &&
                        plan->timing_seen++ % plan->timing_every == 0;
+    if (timed && stream_capturing((hipStream_t)stream))
+        return sm_fail(SM_ERR_ARG, "%s: kernel timing is armed (sm_plan_time_kernels) and the stream is capturing: the "
+                       "timing events of a launch cannot be read back from a graph -- disarm with "
+                       "sm_plan_time_kernels(plan, 0) before the capture begins", me);
     // The bit-sliced kernel's launcher attaches the two events to the dispatch packet itself
     // (the completion signal's own start / end time stamps): no extra packets on the stream.
     // Separate event records cost ~4 us each there, 6 % of a 4K step when every second launch
@@ -1333,16 +1359,7 @@ extern "C" int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uin
     SM_TRY(use_device(plan->device));
     const int b = plan->cur ^ 1;
     hipStream_t lane = plan->lane[b], user = (hipStream_t)stream;
-    if (plan->unfenced || plan->pipelined == 2) {
-        // work already on `stream` that a lane must not overtake: the launches of a sequential phase
-        // (once, both lanes) or, in ordered mode, whatever produces this call's inputs (this lane)
-        SM_HIP(hipEventRecord(plan->ev_inputs, user));
-        SM_HIP(hipStreamWaitEvent(lane, plan->ev_inputs, 0));
-        if (plan->unfenced) SM_HIP(hipStreamWaitEvent(plan->lane[b ^ 1], plan->ev_inputs, 0));
-        plan->unfenced = 0;
-    }
     const unsigned q = plan->seq + 1;
-    if (plan->ev_free_set[(q - 3) & 3]) SM_HIP(hipStreamWaitEvent(lane, plan->ev_free[(q - 3) & 3], 0));
     // what two calls in flight could share: the threshold tables (rebuilt when the threshold
     // changes), the one int32 staging map of the kernels without a narrow store path, and result
     // maps the caller hands to consecutive calls -- any of these puts call q behind call q - 1
@@ -1355,6 +1372,58 @@ extern "C" int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uin
     for (int i = 0; i < 2; i++)
         for (int j = 0; j < 2; j++)
             if (lo[i] < plan->out_hi[j] && plan->out_lo[j] < hi[i]) shared = true;
+
+    unsigned long long cap_id = 0;
+    if (stream_capturing(user, &cap_id)) {
+        // INSIDE A STREAM CAPTURE every operation must descend from the capturing stream and join it again, and no
+        // event recorded outside the capture may be waited for (hipErrorStreamCaptureIsolation -- what round 4's
+        // attempt ran into: its lanes waited for the release events of calls made before the capture began;
+        // tools/capture_probe.hip, profiles/r05/capture_probe.txt).  Protocol: lane b leaves `stream` at ev_fork[b],
+        // which the PREVIOUS captured call recorded before it joined its own lane back -- so call q depends on
+        // everything up to call q - 2 and runs beside call q - 1 in the graph, as outside a capture -- and every
+        // call joins its lane back at once (`stream` waits for its release event), so the capture can end anywhere.
+        // (what cannot be captured is refused BEFORE the lane leaves `stream`: an error must not leave the capture unjoined)
+        if (!(plan->tab_valid && memcmp(&plan->tab_threshold, &threshold, sizeof threshold) == 0))
+            return sm_fail(SM_ERR_ARG, "sm_run: the decision tables of threshold %g are not prepared and the stream is capturing: "
+                           "call sm_plan_prepare_threshold(plan, threshold, stream) before the capture begins", threshold);
+        if (plan->timing_n < plan->timing_cap)
+            return sm_fail(SM_ERR_ARG, "sm_run: kernel timing is armed (sm_plan_time_kernels) and the stream is capturing: "
+                           "disarm with sm_plan_time_kernels(plan, 0) before the capture begins");
+        if (web_type != SM_WEB_I32 && plan->kernel != SM_KERNEL_BS && !plan->d_web_tmp)
+            return sm_fail(SM_ERR_ARG, "sm_run: the int32 staging map of narrow results is not allocated and the stream is "
+                           "capturing: call sm_plan_reserve_narrow(plan) first");
+        const bool first = !plan->cap_live || plan->cap_id != cap_id;
+        if (first) {
+            plan->cap_live = 1;
+            plan->cap_id = cap_id;
+            SM_HIP(hipEventRecord(plan->ev_fork[b], user));
+        }
+        SM_HIP(hipStreamWaitEvent(lane, plan->ev_fork[b], 0));
+        if (shared && !first) SM_HIP(hipStreamWaitEvent(lane, plan->ev_free[(q - 1) & 3], 0));
+        plan->seq = q;
+        plan->cur = b;
+        plan->d_ext = plan->d_ext_buf[b];
+        for (int i = 0; i < 2; i++) { plan->out_lo[i] = lo[i]; plan->out_hi[i] = hi[i]; }
+        SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, (void *)lane));
+        SM_TRY(sm_match_wta_typed(plan, pairs, d_web, web_type, d_best, (void *)lane));   // records ev_free[q & 3] on the lane
+        SM_HIP(hipEventRecord(plan->ev_fork[b ^ 1], user));
+        SM_HIP(hipStreamWaitEvent(user, plan->ev_free[q & 3], 0));
+        // the events of a capture are nodes of its graph: nothing outside it waits for them, and the next call outside a
+        // capture orders its lanes behind `stream` (where the graph is launched, if it is)
+        for (int i = 0; i < 4; i++) plan->ev_free_set[i] = 0;
+        plan->unfenced = 1;
+        return SM_OK;
+    }
+    plan->cap_live = 0;
+    if (plan->unfenced || plan->pipelined == 2) {
+        // work already on `stream` that a lane must not overtake: the launches of a sequential phase
+        // (once, both lanes) or, in ordered mode, whatever produces this call's inputs (this lane)
+        SM_HIP(hipEventRecord(plan->ev_inputs, user));
+        SM_HIP(hipStreamWaitEvent(lane, plan->ev_inputs, 0));
+        if (plan->unfenced) SM_HIP(hipStreamWaitEvent(plan->lane[b ^ 1], plan->ev_inputs, 0));
+        plan->unfenced = 0;
+    }
+    if (plan->ev_free_set[(q - 3) & 3]) SM_HIP(hipStreamWaitEvent(lane, plan->ev_free[(q - 3) & 3], 0));
     if (shared && plan->ev_free_set[(q - 1) & 3]) SM_HIP(hipStreamWaitEvent(lane, plan->ev_free[(q - 1) & 3], 0));
     plan->seq = q;
     plan->cur = b;

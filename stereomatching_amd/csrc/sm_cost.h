@@ -19,16 +19,18 @@ struct SadGeom {
     int rr_stride;           // k_ssd_dot: dwords between the four residue classes of its RR table
     int tbl_pad;             // k_ssd_mfma: dwords between the staged rows and its (16-byte aligned) RR table
     int lds_bytes;
+    int waves;               // k_sad_pc: waves per workgroup (they share the staged rows; the other kernels: 1)
 };
 
 #ifdef __HIPCC__
 // Stage rows ty0 - half .. ty0 - half + nsr - 1 of one pair's two gray images into LDS, [nsr][lrow]
 // bytes of the left image then [nsr][rrow] of the right one, byte 0 of a staged row = image column
 // xw - padl, with the border rule applied: wrap-around (toroidal) or zeros outside the image (ghost).
-// One-wave workgroups (tid < 64).  Shared by the SAD and the SSD kernel.
+// All `nthreads` threads of the workgroup take part (one wave unless said otherwise).  Shared by the SAD and the SSD kernels.
 // `flip` is XORed onto every staged dword (the SSD kernel stages pixel - 128 as signed bytes: 0x80808080).
 __device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ L, const u8 *__restrict__ R,
-                                               const SadGeom &g, int xw, int ty0, int HALF, int tid, u32 flip = 0)
+                                               const SadGeom &g, int xw, int ty0, int HALF, int tid, u32 flip = 0,
+                                               int nthreads = 64)
 {
     const int lw = g.lrow >> 2, rw = g.rrow >> 2;
     if (g.fast_stage) {
@@ -37,13 +39,13 @@ __device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ 
         // or the border test) is done once, and the rows are loaded SR at a time with all loads in
         // flight -- a load, a wait and a store per row and column cost a quarter of the kernel's
         // instructions and left the wave waiting for memory 40 times over.
-        constexpr int SC = 4, SR = 4;                   // (lw + rw <= 256 dwords: checked by the host)
+        constexpr int SC = 4, SR = 4;                   // (lw + rw <= 4 nthreads dwords: checked by the host)
         const u8 *col[SC];
         int dst[SC], dstride[SC];
         bool on[SC];
 #pragma unroll
         for (int c = 0; c < SC; c++) {
-            const int k = tid + 64 * c;
+            const int k = tid + nthreads * c;
             const bool is_r = k >= lw;
             const int kk = is_r ? k - lw : k;
             const int x = xw - g.padl + 4 * kk;
@@ -79,7 +81,7 @@ __device__ __forceinline__ void smc_stage_rows(u32 *lds, const u8 *__restrict__ 
             const int y = ty0 - HALF + row;
             const bool vy = y >= 0 && y < g.h;
             const int ys = g.ghost ? (vy ? y : 0) : ((y % g.h) + g.h) % g.h;
-            for (int k = tid; k < lw + rw; k += 64) {
+            for (int k = tid; k < lw + rw; k += nthreads) {
                 const bool is_r = k >= lw;
                 const int kk = is_r ? k - lw : k;
                 const int x = xw - g.padl + 4 * kk;

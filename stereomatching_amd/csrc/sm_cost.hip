@@ -341,7 +341,18 @@ extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint
         if (!fn && cost == SM_COST_SSD) fn = sm_ssd_dot_configure(plan, pairs, d_gray_left, d_gray_right, &q);
         if (fn) {
             void *args[] = {(void *)&d_gray_left, (void *)&d_gray_right, (void *)&d_web, (void *)&d_best, (void *)&q};
-            const hipError_t e = hipLaunchKernel(fn, dim3(q.tiles_x, q.tiles_y, pairs), dim3(64), args,
+            if (q.lds_bytes > 64 * 1024) {
+                // (four-wave workgroups of k_sad_pc: up to 80 of the CU's 160 KB; the limit is raised once per kernel)
+                static const void *raised[8];
+                static int n_raised = 0;
+                bool seen = false;
+                for (int i = 0; i < n_raised; i++) seen = seen || raised[i] == fn;
+                if (!seen) {
+                    SM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                    if (n_raised < 8) raised[n_raised++] = fn;
+                }
+            }
+            const hipError_t e = hipLaunchKernel(fn, dim3(q.tiles_x, q.tiles_y, pairs), dim3(64 * q.waves), args,
                                                  (size_t)q.lds_bytes, (hipStream_t)stream);
             if (e != hipSuccess) return sm_fail(SM_ERR_HIP, "sm_cost_wta: %s", hipGetErrorString(e));
             // Ghost border: the columns whose windows reach left of the image (x < half), by the masked kernel,

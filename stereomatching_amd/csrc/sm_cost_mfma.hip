@@ -284,7 +284,7 @@ static const void *mfma_ptr(int nb)
 const void *sm_ssd_mfma_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *out)
 {
     SadGeom g;
-    g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
+    g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts; g.waves = 1;
     const int half = plan->square_width / 2, n = 2 * half + 1;
     g.ghost = plan->border == SM_GHOST;
     if (n < 3 || n > 11 || g.D > 256 || plan->opt.cost_kernel == 1 || plan->opt.cost_kernel == 2) return nullptr;

@@ -58,7 +58,7 @@ static __device__ __forceinline__ u64 qsad(u64 r8, u32 l4, u64 acc) { return __b
 typedef u64 __attribute__((aligned(4))) u64a4;
 
 template <int N, int NQL, int PX>
-__global__ __launch_bounds__(64, 2) void k_sad_pc(const u8 *__restrict__ left, const u8 *__restrict__ right,
+__global__ __launch_bounds__(256, 2) void k_sad_pc(const u8 *__restrict__ left, const u8 *__restrict__ right,
                                                   i32 *__restrict__ web, i32 *__restrict__ best,
                                                   const SadGeom g)
 {
@@ -98,10 +98,12 @@ __global__ __launch_bounds__(64, 2) void k_sad_pc(const u8 *__restrict__ left, c
     u32 *sSo = sSn + rw;                                             // [rw]: the old row, likewise
 
     // ---- stage the tile's rows (+ window halo) with the border rule applied
-    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid);
+    // (all waves of the workgroup -- one, two or four, each with its own pixel groups -- stage and share the rows)
+    const int nthreads = blockDim.x;
+    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid, 0, nthreads);
     __syncthreads();
 
-    // ---- lane role: residue a, shift-lane sl, pixel group j
+    // ---- lane role: residue a, shift-lane sl, pixel group j (over all waves)
     const int a = tid & 3;
     const int sl = (tid >> 2) & (g.nl - 1);
     const int j = tid >> (2 + g.log2nl);
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(64, 2) void k_sad_pc(const u8 *__restrict__ left, c
 
         // per right dword position: E = (bytes the zeroed left bytes pick up in the new row) - (old row), and the
         // two rows RB bytes further on
-        for (int k = tid; k < rw - 1; k += 64) {
+        for (int k = tid; k < rw - 1; k += nthreads) {
             const u32 n0 = rowRn[k], n1 = rowRn[k + 1];
             const u64 mn = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)n1 << 32) | n0, MASKC, 0ull);   // 255 (4-RB) - T_new
             sSn[k] = __builtin_amdgcn_alignbyte(n1, n0, RB);
@@ -334,39 +336,77 @@ const void *sm_sad_pc_configure(const sm_plan *plan, int pairs, const void *d_le
     g.nl = 1; g.log2nl = 0;
     while (g.nl * nql < nq) { g.nl <<= 1; g.log2nl++; }
     if (g.nl > 16) return nullptr;
-    g.tw = 4 * px * (16 / g.nl);
-    g.tiles_x = (g.w + g.tw - 1) / g.tw;
     const int ng = n / 4 + 1;
     g.padl = 4 * ((half + 3 + 3) / 4);
-    // left row: dwords up to bL2 + PX - 1 (<= bL + FG + PX) of the last pixel group; right: aligned up to
-    // bR + NQL - 1 + max(NG, PX - 1) + 1, shifted up to bR + NQL - 1 + FG + PX - 1 + 1 (+1: the bytes they are cut from)
-    g.lrow = 8 * ((g.padl + g.tw + 4 * (ng + 3) + 7) / 8);
-    g.rrow = 8 * ((g.padl + g.tw + 4 * (g.nl * nql + ng + px + 2) + 7) / 8);
     g.q_tail = (g.D - 4 * (g.nl - 1) * nql) / 4;
     if (g.q_tail < 0) g.q_tail = 0;
     g.q_last = g.nl > 1 ? nql - 1 : (g.D + 2) / 4;
     if (g.q_last > nql - 1) g.q_last = nql - 1;
-    // tile height: whole rounds of two waves per SIMD; rows + warm-up + staging per workgroup
+    // Workgroup = 1, 2 or 4 waves side by side (each its own 64 / nl pixel groups) sharing the staged rows: with many
+    // shifts a lone wave's tile is narrow (64 pixels at 256 shifts) under a right-image span of 4 (nl nql + ..) bytes,
+    // its 20 KB of LDS hold few rows and the n - 1 warm-up rows weigh a quarter of the launch (C5: 16-row tiles);
+    // four waves share one span and slide 64 rows.  Tile height and workgroup width together: whole rounds of two
+    // waves per SIMD, rows + warm-up (a warm-up row costs ~0.41 of an output row here) + staging per workgroup.
     const int slots = 256 * 4 * 2;
-    int best_th = 0; double best_cost = 0;
-    for (int th = 8; th <= 128; th += 4) {
-        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)g.rrow;
-        if (lds > 160 * 1024 / 8) break;
-        const long long tiles = (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs;
-        const long long rounds = (tiles + slots - 1) / slots;
-        const double cost = (double)rounds * (th + 0.45 * (n - 1) + 2.0);
-        if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
+    int best_th = 0, best_wv = 0; double best_cost = 0;
+    auto row_bytes = [&](int wv, int *lrow, int *rrow) {
+        const int tw = 4 * px * (16 / g.nl) * wv;
+        // left row: dwords up to bL2 + PX - 1 (<= bL + FG + PX) of the last pixel group; right: aligned up to
+        // bR + NQL - 1 + max(NG, PX - 1) + 1, shifted up to bR + NQL - 1 + FG + PX - 1 + 1 (+1: the bytes they are cut from)
+        *lrow = 8 * ((g.padl + tw + 4 * (ng + 3) + 7) / 8);
+        *rrow = 8 * ((g.padl + tw + 4 * (g.nl * nql + ng + px + 2) + 7) / 8);
+        return tw;
+    };
+    for (int wv = 1; wv <= 4; wv *= 2) {
+        int lrow, rrow;
+        const int tw = row_bytes(wv, &lrow, &rrow);
+        if (wv > 1 && tw / 2 >= g.w) break;              // (a workgroup wider than the image)
+        if (lrow + rrow > 4 * 4 * 64 * wv) continue;     // (the fast staging path's reach)
+        const int tiles_x = (g.w + tw - 1) / tw;
+        for (int th = 8; th <= 128; th += 4) {
+            const size_t lds = (size_t)(th + n - 1) * (lrow + rrow) + 4 * (size_t)rrow;
+            if (lds > (size_t)wv * 160 * 1024 / 8) break;
+            const long long waves = (long long)tiles_x * ((g.h + th - 1) / th) * pairs * wv;
+            const long long rounds = (waves + slots - 1) / slots;
+            const double cost = (double)rounds * (th + 0.41 * (n - 1) + 2.0);
+            if (!best_th || cost < best_cost * (wv > best_wv ? 0.97 : 1.0)) { best_th = th; best_wv = wv; best_cost = cost; }
+        }
     }
     if (!best_th) return nullptr;
-    if (plan->opt.cost_tile_h > 0) {         // an explicit tile height, clamped to what a workgroup's LDS holds
-        best_th = plan->opt.cost_tile_h;
-        while (best_th > 1 && (size_t)(best_th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)g.rrow > 64 * 1024) best_th--;
+    int forced_wv = 0;
+    if (plan->opt.cost_workgroup_waves == 1 || plan->opt.cost_workgroup_waves == 2 || plan->opt.cost_workgroup_waves == 4) {
+        int lrow, rrow;                       // an explicit width applies where the staging path reaches it
+        row_bytes(plan->opt.cost_workgroup_waves, &lrow, &rrow);
+        if (lrow + rrow <= 4 * 4 * 64 * plan->opt.cost_workgroup_waves) forced_wv = plan->opt.cost_workgroup_waves;
     }
+    if (forced_wv && forced_wv != best_wv) {
+        // (the height the model gives that width)
+        int lrow, rrow;
+        const int tw = row_bytes(forced_wv, &lrow, &rrow);
+        const int tiles_x = (g.w + tw - 1) / tw;
+        best_th = 0;
+        for (int th = 8; th <= 128; th += 4) {
+            const size_t lds = (size_t)(th + n - 1) * (lrow + rrow) + 4 * (size_t)rrow;
+            if (lds > (size_t)forced_wv * 160 * 1024 / 8) break;
+            const long long waves = (long long)tiles_x * ((g.h + th - 1) / th) * pairs * forced_wv;
+            const long long rounds = (waves + slots - 1) / slots;
+            const double cost = (double)rounds * (th + 0.41 * (n - 1) + 2.0);
+            if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
+        }
+        if (!best_th) best_th = 8;
+        best_wv = forced_wv;
+    }
+    g.waves = best_wv;
+    g.tw = row_bytes(g.waves, &g.lrow, &g.rrow);
+    g.tiles_x = (g.w + g.tw - 1) / g.tw;
+    const size_t lds_cap = (size_t)g.waves * 160 * 1024 / 8;      // (beyond 64 KB: sm_cost_wta raises the kernel's limit)
+    if (plan->opt.cost_tile_h > 0) best_th = plan->opt.cost_tile_h;      // an explicit tile height, clamped to what a workgroup's LDS holds
+    while (best_th > 1 && (size_t)(best_th + n - 1) * (g.lrow + g.rrow) + 4 * (size_t)g.rrow > lds_cap) best_th--;
     g.tile_h = best_th < g.h ? best_th : g.h;
     g.tiles_y = (g.h + g.tile_h - 1) / g.tile_h;
     g.nsr = g.tile_h + n - 1;
     g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0 &&
-                   g.lrow + g.rrow <= 4 * 256;
+                   g.lrow + g.rrow <= 4 * 4 * 64 * g.waves;
     g.lds_bytes = g.nsr * (g.lrow + g.rrow) + 4 * g.rrow;
     g.nql = nql; g.px = px;
     const void *fn = nullptr;

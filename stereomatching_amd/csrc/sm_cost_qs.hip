@@ -327,7 +327,7 @@ const void *sm_sad_qs_configure(const sm_plan *plan, int pairs, const void *d_le
 {
     SadGeom g;
     g.rr_stride = 0; g.tbl_pad = 0;         // (the SSD kernels')
-    g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
+    g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts; g.waves = 1;
     const int half = plan->square_width / 2, n = 2 * half + 1;
     g.ghost = plan->border == SM_GHOST;
     if (n < 3 || n > 21 || g.D > 512 || plan->opt.cost_kernel == 1) return nullptr;     // (512: the entry's own limit)

@@ -322,7 +322,7 @@ static const void *ssd_ptr(int px, bool fulld)
 const void *sm_ssd_dot_configure(const sm_plan *plan, int pairs, const void *d_left, const void *d_right, SadGeom *out)
 {
     SadGeom g;
-    g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts;
+    g.w = plan->width; g.h = plan->height; g.D = plan->num_shifts; g.waves = 1;
     const int half = plan->square_width / 2, n = 2 * half + 1;
     g.ghost = plan->border == SM_GHOST;
     if (n < 3 || n > 11 || g.D > 256 || plan->opt.cost_kernel == 1) return nullptr;

@@ -86,6 +86,9 @@ struct sm_plan {
     hipStream_t lane[2];         // internal: pipelined sm_run i runs (edges, match) on lane i & 1, into buffer i & 1
     hipEvent_t ev_free[4];       // pipelined call number q has finished: ev_free[q & 3]
     hipEvent_t ev_inputs;        // the caller's stream up to this sm_run (pipelined == 2, or after a sequential phase)
+    hipEvent_t ev_fork[2];       // pipelined sm_run INSIDE A STREAM CAPTURE: where lane b leaves the capturing stream
+    unsigned long long cap_id;   // ... the capture these belong to (hipStreamGetCaptureInfo)
+    int cap_live;                // ... the last pipelined sm_run was captured
     int ev_free_set[4];
     unsigned seq;                // number of the current / last pipelined sm_run
     int unfenced;                // match launches went out without a release event

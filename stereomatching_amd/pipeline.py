@@ -101,6 +101,13 @@ class StereoPlan:
         """Threshold-only set-up of find_all_edges (it does this itself on first use)."""
         check(lib.sm_plan_prepare_threshold(self._h, float(threshold), self._stream()))
 
+    def reserve_narrow(self):
+        """The int32 staging map that uint8 / uint16 results of the fallback kernels go through, allocated now
+        (a no-op for plans whose kernel stores narrow maps itself): keeps the allocation out of timed paths and
+        out of stream captures."""
+        check(lib.sm_plan_reserve_narrow(self._h))
+        self._narrow_ready = True
+
     def time_kernels(self, capacity: int, every: int = 1):
         """Bracket every `every`-th of the coming match launches (at most `capacity` of
         them) with HIP events on the launch stream."""
@@ -178,6 +185,9 @@ class StereoPlan:
         pairs = left.shape[0]
         web = self._out(web, pairs, "web", web_dtype)
         best = self._out(best, pairs, "best") if want_best else None
+        if web_dtype != torch.int32 and not getattr(self, "_narrow_ready", False) and \
+                not torch.cuda.is_current_stream_capturing():
+            self.reserve_narrow()       # (inside a capture the library says what to call first)
         check(lib.sm_run_typed(self._h, _ptr(left), _ptr(right), float(threshold), pairs, _ptr(web),
                                WEB_TYPES[web_dtype], _ptr(best if want_best else None), self._stream()))
         return web, (best if want_best else None)

@@ -643,6 +643,89 @@ def test_pipelined_runs_and_kernel_timing(hip):
     plan.close()
 
 
+def test_runs_captured_into_a_graph(hip):
+    """sm_run inside a stream capture (torch.cuda.graph; include/stereo_hip.h "STREAM CAPTURE"): a plain plan and a
+    PIPELINED one -- whose lanes must leave and rejoin the capturing stream by events recorded inside the capture; round 4's
+    attempt crashed the process -- replay to the oracle's maps, also after eager calls in between; what cannot be
+    captured (threshold tables not built, timing armed, the narrow staging map not allocated) is refused with a message
+    that names the remedy and leaves the capture usable."""
+    w, h, d, sw = 320, 200, 64, 7
+    pairs = [make_pair(w, h, d, seed=70 + i) for i in range(4)]
+    inputs = [(dev(l), dev(r)) for l, r in pairs]
+    want = [oracle.pipeline(l, r, 0.15, d, sw, step3=False)["web-1"] for l, r in pairs]
+    for pipelined in (False, True):
+        plan = hip.StereoPlan(w, h, d, sw)
+        plan.prepare_threshold(0.15)
+        plan.run(*inputs[0], 0.15)
+        plan.set_pipelined(pipelined)
+        for a, b in inputs:               # (pipelined: eager calls whose release events exist before the capture begins)
+            plan.run(a, b, 0.15)
+        torch.cuda.synchronize()
+        webs = [torch.zeros((1, h, w), dtype=torch.int32, device="cuda") for _ in inputs]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for (a, b), o in zip(inputs, webs):
+                plan.run(a, b, 0.15, web=o)
+        for rep in range(3):
+            for o in webs:
+                o.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            for o, exp in zip(webs, want):
+                assert np.array_equal(host(o)[0], exp), (pipelined, rep)
+            got = plan.run(*inputs[rep], 0.15)[0]           # an eager call between replays
+            torch.cuda.synchronize()
+            assert np.array_equal(host(got)[0], want[rep]), (pipelined, rep)
+        # refused, cleanly
+        plan.time_kernels(2)
+        with pytest.raises(hip.capi.StereoHipError, match="sm_plan_time_kernels"):
+            with torch.cuda.graph(torch.cuda.CUDAGraph(), capture_error_mode="thread_local"):
+                plan.run(*inputs[0], 0.15)
+        plan.time_kernels(0)
+        with pytest.raises(hip.capi.StereoHipError, match="sm_plan_prepare_threshold"):
+            with torch.cuda.graph(torch.cuda.CUDAGraph(), capture_error_mode="thread_local"):
+                plan.run(*inputs[0], 0.33)
+        # ... and the plan still works, captured and eager
+        g2 = torch.cuda.CUDAGraph()
+        o2 = torch.zeros((1, h, w), dtype=torch.int32, device="cuda")
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+            plan.run(*inputs[2], 0.15, web=o2)
+        g2.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(host(o2)[0], want[2])
+        assert np.array_equal(host(plan.run(*inputs[3], 0.15)[0])[0], want[3])
+        plan.close()
+    # the narrow staging map of a fallback kernel: an allocation, not capturable
+    plan = hip.StereoPlan(w, h, d, sw, options=dict(kernel_family=1))
+    plan.prepare_threshold(0.15)
+    plan.run(*inputs[0], 0.15)
+    torch.cuda.synchronize()
+    o8 = torch.zeros((1, h, w), dtype=torch.uint8, device="cuda")
+    with pytest.raises(hip.capi.StereoHipError, match="sm_plan_reserve_narrow"):
+        with torch.cuda.graph(torch.cuda.CUDAGraph(), capture_error_mode="thread_local"):
+            plan.run(*inputs[0], 0.15, web=o8, web_dtype=torch.uint8)
+    plan.reserve_narrow()
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3, capture_error_mode="thread_local"):
+        plan.run(*inputs[1], 0.15, web=o8, web_dtype=torch.uint8)
+    g3.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(host(o8)[0].astype(np.int32), want[1])
+    plan.close()
+    # the SAD / SSD cost mode captures as any launch
+    plan = hip.StereoPlan(w, h, d, 9)
+    l, r = inputs[0]
+    ref_web, ref_best = plan.cost_wta(l, r, "sad")
+    cw, cb = torch.zeros_like(ref_web), torch.zeros_like(ref_best)
+    g4 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g4, capture_error_mode="thread_local"):
+        plan.cost_wta(l, r, "sad", web=cw, best=cb)
+    g4.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cw, ref_web) and torch.equal(cb, ref_best)
+    plan.close()
+
+
 def test_c_abi_three_streams_chained_with_events(hip):
     """uploads, kernels and downloads on a stream each (the pattern of stereopar_batch.c and
     tools/e2e_bench.py): 12 DIFFERENT 1080p pairs through 3 buffer sets; sm_event_record /

@@ -22,6 +22,7 @@ NAMES = {
     "SM_LANE_MERGE": lambda v: {"lane_merge": int(v)},
     "SM_NO_DS4": lambda v: {"no_four_shift_lanes": int(v)},
     "SM_PRIO_UNIT": lambda v: {"priority_unit_log2": int(v)},
+    "SM_COST_WAVES": lambda v: {"cost_workgroup_waves": int(v)},
 }
 
 
@@ -42,7 +43,7 @@ class PlanOptions(C.Structure):     # sm_plan_options, for tools that load a lib
                 ("priority_pattern", C.c_uint), ("edge_kernel", C.c_int), ("timing_by_records", C.c_int),
                 ("cost_pixels_per_lane", C.c_int), ("cost_tile_h", C.c_int), ("cost_kernel", C.c_int),
                 ("priority_class", C.c_int), ("priority_on_change", C.c_int), ("lane_merge", C.c_int),
-                ("no_four_shift_lanes", C.c_int), ("priority_unit_log2", C.c_int)]
+                ("no_four_shift_lanes", C.c_int), ("priority_unit_log2", C.c_int), ("cost_workgroup_waves", C.c_int)]
 
 
 def struct_from_spec(spec: dict) -> PlanOptions:
