@@ -106,6 +106,9 @@ def parse(argv=None):
                          "own timing events (every 8th, every 2nd at --steps 20)")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region, collect the maps on rank 0 over RCCL and time it")
+    ap.add_argument("--no-c2", action="store_true", help="skip the extra `c2` object (N = 1): BASELINE's second single-GPU "
+                                                           "configuration (1080p pair, 64 shifts, 7x7), never part of `value`")
+    ap.add_argument("--corrupt-map", action="store_true", help=argparse.SUPPRESS)     # test hook: the verification must notice
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the extra `e2e` object (N = 1 only): the PCIe-inclusive rate through the "
                          "C ABI alone (pinned buffers, async copies), measured after the timed region; "
@@ -171,45 +174,93 @@ def launch_ranks(n: int, argv: list[str]) -> int:
     return rc
 
 
-def cpu_baseline(w, d, sw, mode, rows, threshold):
-    """Time the oracle's faithful port (same loop nest and modulo indexing as
-    stereo.c) on a full-width band of `rows` rows of the workload."""
-    from stereomatching_amd.synth import make_pair
-    from tests import oracle    # checker: the only place bench.py touches oracle/
-
-    left, right = make_pair(w, rows, d, seed=9)
+def oracle_band(left, right, y0, rows, d, sw, mode, threshold, faithful=False):
+    """web rows y0 .. y0 + rows - 1 of a full image pair by the CPU oracle: the band with a halo of
+    half + 1 rows either side (edges need one row, the window `half`), full width.  -> (web band, seconds)"""
+    from tests import oracle    # checker: bench.py touches oracle/ here and in cost_band only
+    import numpy as np
+    h = left.shape[0]
+    halo = sw // 2 + 1
+    idx = np.arange(y0 - halo, y0 + rows + halo)
+    assert mode == "toroidal" or (idx[0] >= 0 and idx[-1] < h), "ghost band must lie inside the image"
+    idx %= h
+    sub_l, sub_r = np.ascontiguousarray(left[idx]), np.ascontiguousarray(right[idx])
     t0 = oracle.lib().smo_time()
-    el = oracle.find_all_edges(left, threshold, mode)
-    er = oracle.find_all_edges(right, threshold, mode)
-    oracle.hot_path(el, er, d, sw, mode, faithful=True)
+    el = oracle.find_all_edges(sub_l, threshold, mode)
+    er = oracle.find_all_edges(sub_r, threshold, mode)
+    _, web = oracle.hot_path(el, er, d, sw, mode, faithful=faithful)
     dt = oracle.lib().smo_time() - t0
+    return web[halo:halo + rows], dt, (el, er)
+
+
+def cost_band(left, right, y0, rows, d, sw, mode, cost):
+    """the same for the SAD / SSD cost mode (the build's own CPU definition) -> (best band, web band)"""
+    from tests import oracle
+    import numpy as np
+    h = left.shape[0]
+    half = sw // 2
+    idx = np.arange(y0 - half, y0 + rows + half)
+    assert mode == "toroidal" or (idx[0] >= 0 and idx[-1] < h)
+    idx %= h
+    best, web = oracle.cost_hot_path(np.ascontiguousarray(left[idx]), np.ascontiguousarray(right[idx]), d, sw, mode, cost)
+    return best[half:half + rows], web[half:half + rows]
+
+
+def cpu_baseline(left, right, y0, d, sw, mode, rows, threshold):
+    """Time the oracle's faithful port (same loop nest and modulo indexing as stereo.c) on a full-width band of
+    `rows` rows (+ halo) of the workload's own first pair.  -> (the object, the oracle's web of that band)"""
+    from tests import oracle    # checker
+    w = left.shape[1]
+    web, dt, (el, er) = oracle_band(left, right, y0, rows, d, sw, mode, threshold, faithful=True)
+    computed = el.shape[0]
     out = {
-        "value": round(w * rows * d / dt / 1e6, 3),
+        "value": round(w * computed * d / dt / 1e6, 3),
         "unit": "Mpixel-disparities/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{w}x{rows} band (full width, all {d} shifts, S={sw}, {mode}) of the workload, "
-                  f"{dt:.1f} s single-threaded; host has {os.cpu_count()} cores",
+        "sample": f"rows {y0} .. {y0 + rows - 1} (+ {computed - rows} halo rows) of the workload's first pair: {w}x{computed} "
+                  f"pixels, full width, all {d} shifts, S={sw}, {mode}; {dt:.1f} s single-threaded; "
+                  f"host has {os.cpu_count()} cores",
     }
-    # the same band on every host core at once (independent bands, as a batch of pairs
-    # would be spread over processes; ctypes releases the GIL around the C call)
+    # Independent bands on many host cores at once (as a batch of pairs would be spread over processes; ctypes releases
+    # the GIL around the C call).  How many cores this process may really use is not what os.cpu_count() says on a
+    # shared box (round 4 ran 64 threads and called it "all cores"; 256 threads on this pool's 16-core share take
+    # 2.5 minutes): the thread count is doubled from 16 while the rate still grows, and the line says what was tried.
     import threading
-    workers = max(1, min(os.cpu_count() or 1, 64))
-
-    hr = max(sw, rows // 2)             # half the band per worker keeps this leg ~20 s
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    hr = max(sw, 24)
 
     def job():
         oracle.hot_path(el[:hr], er[:hr], d, sw, mode, faithful=True)
-    ts = [threading.Thread(target=job) for _ in range(workers)]
-    t0 = oracle.lib().smo_time()
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    dta = oracle.lib().smo_time() - t0
-    out["all_cores"] = {"value": round(workers * w * hr * d / dta / 1e6, 2), "cores": workers,
-                        "sample": f"{workers} concurrent {w}x{hr} bands (hot path only), {dta:.1f} s"}
-    return out
+    tried, best_rate, best_t = {}, 0.0, 1
+    t = min(16, usable)
+    while True:
+        ts = [threading.Thread(target=job) for _ in range(t)]
+        t0 = oracle.lib().smo_time()
+        for th in ts:
+            th.start()
+        for th in ts:
+            th.join()
+        rate = t * w * hr * d / (oracle.lib().smo_time() - t0) / 1e6
+        tried[str(t)] = round(rate, 1)
+        grew = rate > 1.15 * best_rate
+        if rate > best_rate:
+            best_rate, best_t = rate, t
+        if not grew or t >= usable:
+            break
+        t = min(2 * t, usable)
+    out["all_cores"] = {"value": round(best_rate, 2), "cores": best_t, "usable_cores": usable,
+                        "rate_by_threads": tried,
+                        "sample": f"concurrent {w}x{hr} bands (hot path only), one per thread; threads doubled from 16 while "
+                                  f"the rate grew by more than 15 %; affinity / cgroup allow {usable} cores, "
+                                  f"os.cpu_count() = {os.cpu_count()}"}
+    return out, web
 
 
 def cost_modes(dev):
@@ -248,9 +299,22 @@ def cost_modes(dev):
         e1.record()
         torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / launches
+        # what was timed is checked: the map the LAST timed launch wrote (pair (launches - 1) % 2), a full-width band of it
+        # against the build's own CPU definition, and best of a launch of its own
+        vy0, vrows = h // 2, COST_VERIFY_ROWS
+        k = (launches - 1) % 2
+        _, ow = cost_band(ls[k], rs[k], vy0, vrows, d, sw, mode, cost)
+        ok_band = bool(np.array_equal(web[0, vy0:vy0 + vrows].cpu().numpy(), ow))
+        wb, bb = plan.cost_wta(L[k], R[k], cost, want_best=True)
+        ob, _ = cost_band(ls[k], rs[k], vy0, 4, d, sw, mode, cost)
+        ok_best = bool(torch.equal(wb, web)) and bool(np.array_equal(bb[0, vy0:vy0 + 4].cpu().numpy(), ob))
         o = {
             "workload": f"{cfg}: {w}x{h} pair, {d} shifts, {sw}x{sw} {cost.upper()} window cost, {mode} border; "
                         "uint8 gray in, int32 web out",
+            "verified": ok_band and ok_best,
+            "verified_how": f"rows {vy0} .. {vy0 + vrows - 1} of the map the last timed launch wrote equal the build's own CPU "
+                            f"definition ({ok_band}); a further launch with `best` gives the same web and the definition's "
+                            f"best on 4 rows ({ok_best})",
             "parity": "UNPINNED: no reference implementation exists (SURVEY.md 0, 8f4); checked against the "
                       "build's own CPU definition only",
             "ms_per_launch": round(ms, 4),
@@ -277,6 +341,96 @@ def cost_modes(dev):
         res[key] = o
         plan.close()
     return res
+
+
+COST_VERIFY_ROWS = 16
+
+
+def small_config_leg(dev, cfg, threshold, use_graph):
+    """The extra `c2` object (N = 1): BASELINE.json's other single-GPU configuration -- a lone 1080p pair, 64 shifts,
+    7 x 7 -- through the same step as the headline (edges + fused match -> web, inputs resident), replayed from a HIP
+    graph like the headline's steps; the host-launched rate beside it.  Never part of `value`."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from stereomatching_amd import pipeline
+    from stereomatching_amd.synth import CONFIGS, make_pair
+
+    w, h, d, sw, mode = CONFIGS[cfg]
+    resident, gsteps, steps = 4, 100, 400
+    plan = pipeline.StereoPlan(w, h, d, sw, mode, device=dev.index)
+    plan.prepare_threshold(threshold)
+    prs = [make_pair(w, h, d, seed=2000 + j) for j in range(resident)]
+    L = torch.from_numpy(np.stack([p[0] for p in prs])).to(dev)
+    R = torch.from_numpy(np.stack([p[1] for p in prs])).to(dev)
+    web = torch.zeros((resident, h, w), dtype=torch.int32, device=dev)
+    lib, check = pipeline.capi.lib, pipeline.capi.check
+
+    def step(k, st, out=None):
+        o = web if out is None else out
+        check(lib.sm_run(plan._h, C.c_void_p(L[k].data_ptr()), C.c_void_p(R[k].data_ptr()), threshold, 1,
+                         C.c_void_p(o[k].data_ptr()), C.c_void_p(0), st))
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for k in range(resident):
+        step(k, stream)
+    torch.cuda.synchronize(dev)
+    graph, note = None, None
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                cs = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for i in range(gsteps):
+                    step(i % resident, cs)
+        except Exception as exc:      # noqa: BLE001
+            graph, note = None, f"capture failed ({type(exc).__name__})"
+            torch.cuda.synchronize(dev)
+
+    def run(n):
+        if graph is not None:
+            for _ in range(n // gsteps):
+                graph.replay()
+        else:
+            for i in range(n):
+                step(i % resident, stream)
+    t_end = time.perf_counter() + WARMUP_FLOOR_S
+    while time.perf_counter() < t_end:
+        run(gsteps)
+        torch.cuda.synchronize(dev)
+    web.zero_()
+    run(gsteps)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    timed = web.clone()
+    # host-launched, step by step
+    for i in range(16):
+        step(i % resident, stream)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i % resident, stream)
+    torch.cuda.synchronize(dev)
+    ms_host = (time.perf_counter() - t0) / steps * 1e3
+    chk = torch.empty_like(web)
+    for k in range(resident):
+        step(k, stream, chk)
+    torch.cuda.synchronize(dev)
+    vy0, vrows = h // 2, 32
+    ow, _, _ = oracle_band(prs[0][0], prs[0][1], vy0, vrows, d, sw, mode, threshold)
+    ok = bool(torch.equal(timed, chk)) and bool(np.array_equal(timed[0, vy0:vy0 + vrows].cpu().numpy(), ow))
+    text = plan.describe()
+    plan.close()
+    return {"workload": f"{cfg}: {w}x{h} pair, {d} shifts, {sw}x{sw} window, {mode} border, 1 pair/step; edges + fused "
+                        "match/aggregate/WTA -> web, inputs resident",
+            "ms_per_step": round(ms, 4), "value": round(float(w) * h * d / ms / 1e3, 1), "unit": "Mpixel-disparities/s",
+            "steps": steps, "timed_steps": f"{gsteps} steps per HIP graph" if graph is not None else (note or "launched from the host"),
+            "host_launched_ms_per_step": round(ms_host, 4), "kernel": text,
+            "verified": ok,
+            "verified_how": f"the {resident} maps the timed steps left equal host-launched runs; rows {vy0} .. {vy0 + vrows - 1} "
+                            "of the first equal the CPU oracle"}
 
 
 C4_TOTAL_PAIRS = 64
@@ -526,7 +680,7 @@ def main():
 
     # --graph: `gsteps` consecutive steps (a whole number of turns over the resident batches) captured once
     graph, gsteps, graph_note = None, 0, None
-    if args.graph and not args.pipeline and args.steps >= resident:
+    if args.graph and args.steps >= resident:
         try:
             gsteps = max(resident, min(args.steps, 100) // resident * resident)
             for _ in range(2):                     # (code objects loaded, tables built: nothing lazy inside the capture)
@@ -587,6 +741,7 @@ def main():
     # region (a timed region of 20 steps is only 2 ms long; without the burst its first
     # launches ran ~10 % slower and the line read 0.099 ms per step where 200 steps read 0.0955)
     burst = gsteps if graph is not None else WARMUP_BURST
+    web.zero_()                 # what the maps hold after the timed region was written by the burst or the timed steps
     run_steps(burst)
     warm_steps += burst
     if graph is None:
@@ -599,6 +754,9 @@ def main():
     torch.cuda.synchronize(dev)
     shard.barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, red_dev)
+    web_timed = web.clone()     # the maps as the timed steps left them (checked below, outside the timed region)
+    if args.corrupt_map:
+        web_timed[0, h // 2 + 3, 17] ^= 1
 
     if graph is not None:
         # (hipEventRecordWithFlags(..., hipEventRecordExternal) inside the capture is refused by this runtime:
@@ -612,6 +770,40 @@ def main():
     assert n_timed == n_samples, (n_timed, n_samples)
     units_per_step = float(w) * h * d * pairs                      # pixel-disparities / rank
     value = units_per_step * world * args.steps / elapsed / 1e6
+
+    # ---- what was timed is checked (outside the timed region) ----------------------------------------------------
+    # (a) every resident result map, as the timed steps (graph replays by default) left it, equals the map of a
+    #     host-launched, unpipelined sm_run on the same inputs: compared on the device
+    plan.time_kernels(0)
+    plan.set_pipelined(False)
+    torch.cuda.synchronize(dev)
+    chk = torch.empty_like(web)
+    for k in range(resident):
+        check(lib.sm_run(plan._h, p_l[k], p_r[k], args.threshold, pairs, C.c_void_p(chk.data_ptr() + k * mp),
+                         C.c_void_p(0), stream))
+    torch.cuda.synchronize(dev)
+    same_as_host_launched = bool(torch.equal(web_timed, chk))
+    host_launched = None
+    if graph is not None or args.pipeline:
+        # ... and the rate of the plain host-launched path beside the default's (both in the line)
+        turn[0] = 0
+        n_hl = max(resident, min(args.steps, 200))
+        for _ in range(WARMUP_BURST):
+            step()
+        torch.cuda.synchronize(dev)
+        h0 = time.perf_counter()
+        for _ in range(n_hl):
+            step()
+        torch.cuda.synchronize(dev)
+        host_launched = {"ms_per_step": round((time.perf_counter() - h0) / n_hl * 1e3, 4), "steps": n_hl,
+                         "note": "every step launched from the host, no overlap; this rank only, outside the timed region"}
+    # (b) a full-width band of the first map against the CPU oracle (rank 0, below: the cpu_baseline leg's own band)
+    verify_rows = min(args.cpu_rows, 48) if (args.no_cpu_baseline or world > 1) else args.cpu_rows
+    verify_rows = max(1, min(verify_rows, h - 2 * (sw // 2 + 1)))
+    vy0 = max(sw // 2 + 1, min(h // 2, h - verify_rows - sw // 2 - 1))
+    band_gpu = web_timed[0, vy0:vy0 + verify_rows].cpu().numpy()
+    ranks_differing = shard.max_over_ranks(0.0 if same_as_host_launched else 1.0, red_dev)
+    del web_timed, chk
 
     gather_ms = None
     if args.gather and (world > 1 or selftest):
@@ -633,6 +825,8 @@ def main():
 
     if rank != 0:
         shard.finalize()
+        if not same_as_host_launched:
+            sys.exit(3)
         return
 
     kernel_s = kernel_ms * 1e-3
@@ -664,6 +858,7 @@ def main():
         "traffic_source": traffic_src,
         "kernel_ms": round(kernel_ms, 4),
         "kernel_launches_timed": n_timed,
+        "kernel_ms_sampled_outside_timed_region": graph is not None,
         "kernel_ms_method": ("start / end time stamps of the dispatch itself (hipExtLaunchKernel events: the "
                              "clock rocprofv3's kernel trace reads), on the launch stream"
                              if "bit-sliced" in plan_text else
@@ -721,8 +916,14 @@ def main():
             "pipelined": args.pipeline,
             "graph": f"{gsteps} steps per HIP graph" if graph is not None else (graph_note or False),
         },
+        "timed_steps": ("replayed from HIP graphs" if graph is not None else "launched from the host") +
+                       ("; consecutive steps overlapped on the plan's two lanes" if args.pipeline else ""),
+        "graph_capture": "ok" if graph is not None else ("not asked for" if not args.graph or args.steps < resident
+                                                         else (graph_note or "failed")),
         "roofline": roof,
     }
+    if host_launched is not None:
+        out["host_launched"] = host_launched
     if rehearsal:
         out["rehearsal"] = "SM_BENCH_REHEARSAL: all ranks on device 0 over gloo"
     if gather_ms is not None:
@@ -731,15 +932,37 @@ def main():
         out["e2e"] = e2e
     if c4 is not None:
         out["c4"] = c4
+    if c4 is None:
+        plan.close()
+        del left, right, web
+        torch.cuda.empty_cache()
+    if world == 1 and not args.no_c2 and not rehearsal and args.config != "C2":
+        out["c2"] = small_config_leg(dev, "C2", args.threshold, args.graph)
     if world == 1 and not args.no_cost_modes and not rehearsal:
-        if c4 is None:
-            plan.close()
-            del left, right, web
         out.update(cost_modes(dev))
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(w, d, sw, mode, args.cpu_rows, args.threshold)
+        out["cpu_baseline"], oweb = cpu_baseline(lefts[0], rights[0], vy0, d, sw, mode, verify_rows, args.threshold)
+        how = "the cpu_baseline leg's own band"
+    else:
+        oweb, _, _ = oracle_band(lefts[0], rights[0], vy0, verify_rows, d, sw, mode, args.threshold)
+        how = "the CPU oracle's separable path"
+    band_ok = bool(np.array_equal(band_gpu, oweb))
+    extras_ok = all(o.get("verified", True) for o in out.values() if isinstance(o, dict))
+    out["verified"] = bool(ranks_differing == 0.0 and band_ok and extras_ok)
+    out["verification"] = {
+        "maps_equal_host_launched_runs": ranks_differing == 0.0,
+        "band_equals_cpu_oracle": band_ok,
+        "extras_verified": extras_ok,
+        "how": f"after the timed region: all {resident} resident result maps, as the timed steps left them (zeroed in front "
+               f"of the last untimed burst), equal (torch.equal, on the device, every rank) the maps of host-launched "
+               f"unpipelined sm_run calls on the same inputs; rows {vy0} .. {vy0 + verify_rows - 1} of the first one equal "
+               f"{how} on the same pair; the `c2` / `sad` / `ssd` objects carry their own checks",
+    }
     emit(json.dumps(out))
     shard.finalize()
+    if not out["verified"]:
+        print("bench.py: VERIFICATION FAILED: " + json.dumps(out["verification"]), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

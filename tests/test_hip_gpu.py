@@ -1548,3 +1548,35 @@ def test_bench_line_with_and_without_graph_replay(flags, graph):
     assert bool(out["config"]["graph"]) == graph, out["config"]["graph"]
     assert out["roofline"]["kernel_launches_timed"] >= 10
     assert 0.3 < out["roofline"]["frac"] < 1.0 and out["roofline"]["kernel_ms"] < out["ms_per_step"]
+    assert out["verified"] is True and out["verification"]["maps_equal_host_launched_runs"] is True
+    assert out["graph_capture"] == ("ok" if graph else "not asked for")
+    if graph:
+        assert out["host_launched"]["ms_per_step"] > 0 and out["c2"]["verified"] is True and out["c2"]["value"] > 1e6
+
+
+@pytest.mark.parametrize("flags", [[], ["--pipeline"]])
+def test_bench_checks_what_it_timed(flags):
+    """bench.py compares the result maps its timed steps left (graph replays by default; with --pipeline: consecutive
+    steps overlapped INSIDE the graph) with host-launched runs on the device and with the CPU oracle on a band, says
+    `verified` in its line and exits non-zero otherwise: a map corrupted behind the timed region (a test hook) must
+    be noticed."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    base = [sys.executable, str(root / "bench.py"), "--config", "C2", "--steps", "8", "--warmup", "2", "--no-e2e",
+            "--no-cost-modes", "--cpu-rows", "12", *flags]
+    p = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][0]
+    assert out["verified"] is True and out["verification"]["band_equals_cpu_oracle"] is True
+    assert out["graph_capture"] == "ok" and out["cpu_baseline"]["value"] > 0
+    ac = out["cpu_baseline"]["all_cores"]
+    assert ac["value"] > 0 and 1 <= ac["cores"] <= ac["usable_cores"] and str(ac["cores"]) in ac["rate_by_threads"]
+    p = subprocess.run(base + ["--corrupt-map", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    out = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][0]
+    assert out["verified"] is False and "VERIFICATION FAILED" in p.stderr
