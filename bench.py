@@ -589,7 +589,25 @@ def main():
     # SM_BENCH_NCCL_SELFTEST=1: create the RCCL process group even for one rank, so that a
     # 1-GPU box runs the broadcast / barrier / all-reduce / gather calls of the N > 1 path
     selftest = os.environ.get("SM_BENCH_NCCL_SELFTEST") == "1"
-    rank, local_rank, world = shard.init("gloo" if rehearsal else None, force=selftest)
+    def fail_line(msg: str, code: int) -> None:
+        """a job that cannot run still answers: rank 0 (or whoever would have been it) prints a line with `error`"""
+        print(f"bench.py: {msg}", file=sys.stderr)
+        if int(os.environ.get("RANK", "0")) == 0:
+            emit(json.dumps({"metric": "Mpixel-disparities/s", "value": 0.0, "unit": "Mpixel-disparities/s",
+                             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "verified": False,
+                             "error": msg, "config": {"workload": f"{args.config} (not run)"}}))
+        sys.exit(code)
+
+    try:
+        rank, local_rank, world = shard.init("gloo" if rehearsal else None, force=selftest,
+                                             timeout_s=float(os.environ.get("SM_BENCH_INIT_TIMEOUT", "120")))
+        if world > 1 or selftest:
+            # the communicator itself comes up in the first collective (RCCL is lazy): do it here, under the time limit
+            # and by name, not somewhere inside the warm-up
+            shard.barrier()
+    except Exception as exc:      # noqa: BLE001 -- InitError, or the first barrier's failure
+        fail_line(f"{type(exc).__name__}: {exc}", 4)
     if rehearsal:
         local_rank = 0
     if world != args.gpus:

@@ -98,6 +98,11 @@ int sm_event_sync(int device, void *event);
  * not with this library.  (A host that wants its maps in HOST memory is better served by one download
  * per device -- n PCIe links instead of one -- which is what host/stereopar_batch.c does.)            */
 typedef struct sm_comm sm_comm;
+/* The RCCL build to load instead of the default names (librccl.so.1, librccl.so, /opt/rocm/lib/librccl.so.1): a path,
+ * before the first sm_comm_create of the process.  A library that exports the symbol sm_rccl_host_stand_in is taken
+ * for a HOST stand-in (tests/rccl_stub.c): its communicators are driven with host buffers and no device is touched,
+ * which is how the grouped send / receive order of sm_gather_maps is rehearsed where fewer than two GPUs exist.      */
+int sm_comm_set_rccl_library(const char *path);
 int sm_comm_create(const int *devices, int n, sm_comm **out);     /* every device at most once */
 void sm_comm_destroy(sm_comm *comm);
 int sm_comm_size(const sm_comm *comm);
@@ -185,7 +190,12 @@ typedef struct sm_geometry {
     int lane_merge_lds;      /* bit-sliced kernel: the lanes that split a word's shift range are merged through LDS
                               * every four rows (1) or per row with DPP (0) */
 } sm_geometry;
+/* sm_plan_geometry writes sizeof(sm_geometry) bytes AS THIS HEADER DECLARES IT: the struct grows at its end from
+ * release to release, so a caller that may meet a newer library than the header it was compiled against (bindings,
+ * plug-ins) passes the size of ITS struct to sm_plan_geometry_sized -- the fields it knows are filled in, nothing is
+ * written past them; a struct newer than the library gets its unknown tail zeroed.                               */
 int sm_plan_geometry(const sm_plan *plan, sm_geometry *out);
+int sm_plan_geometry_sized(const sm_plan *plan, sm_geometry *out, size_t size_of_callers_struct);
 /* bytes of private device workspace */
 size_t sm_plan_workspace_bytes(const sm_plan *plan);
 /* Narrow result maps (sm_match_wta_typed / sm_run_typed with SM_WEB_U8 / SM_WEB_U16) of the kernels that

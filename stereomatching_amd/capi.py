@@ -81,6 +81,7 @@ _SIGNATURES = {
     "sm_event_record": (_int, [_int, _vp, _vp]),
     "sm_stream_wait_event": (_int, [_int, _vp, _vp]),
     "sm_event_sync": (_int, [_int, _vp]),
+    "sm_comm_set_rccl_library": (_int, [C.c_char_p]),
     "sm_comm_create": (_int, [_intp, _int, C.POINTER(_vp)]),
     "sm_comm_destroy": (None, [_vp]),
     "sm_comm_size": (_int, [_vp]),
@@ -93,6 +94,7 @@ _SIGNATURES = {
     "sm_plan_workspace_bytes": (_sz, [_vp]),
     "sm_plan_reserve_narrow": (_int, [_vp]),
     "sm_plan_geometry": (_int, [_vp, C.POINTER(Geometry)]),
+    "sm_plan_geometry_sized": (_int, [_vp, C.POINTER(Geometry), _sz]),
     "sm_find_edges": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp]),
     "sm_load_edges": (_int, [_vp, _vp, _vp, _int, _vp]),
     "sm_match_wta": (_int, [_vp, _int, _vp, _vp, _vp]),

@@ -987,9 +987,12 @@ extern "C" void sm_plan_destroy(sm_plan *plan)
 
 extern "C" const char *sm_plan_describe(const sm_plan *plan) { return plan ? plan->describe : ""; }
 
-extern "C" int sm_plan_geometry(const sm_plan *plan, sm_geometry *out)
+extern "C" int sm_plan_geometry_sized(const sm_plan *plan, sm_geometry *out_any, size_t size)
 {
-    if (!plan || !out) return sm_fail(SM_ERR_ARG, "sm_plan_geometry: NULL argument");
+    if (!plan || !out_any) return sm_fail(SM_ERR_ARG, "sm_plan_geometry: NULL argument");
+    if (size < sizeof(int)) return sm_fail(SM_ERR_ARG, "sm_plan_geometry_sized: size %zu is not that of a sm_geometry", size);
+    sm_geometry full, *out = &full;
+    memset(&full, 0, sizeof full);
     const MatchGeom &g = plan->g;
     out->kernel = plan->kernel;
     out->window = g.n;
@@ -1008,7 +1011,15 @@ extern "C" int sm_plan_geometry(const sm_plan *plan, sm_geometry *out)
     out->edge_rows_per_wave = (g.w % 4 == 0) ? SM_EDGE4_ROWS : SM_EDGE_ROWS;
     out->waves_per_workgroup = plan->kernel == SM_KERNEL_BS ? (g.duo ? 2 : 1) : (g.threads + 63) / 64;
     out->lane_merge_lds = plan->kernel == SM_KERNEL_BS && g.xmerge;
+    // the caller's struct may be older (shorter: it gets the fields it knows) or newer (longer: the rest is zeroed)
+    memset(out_any, 0, size);
+    memcpy(out_any, &full, size < sizeof full ? size : sizeof full);
     return SM_OK;
+}
+
+extern "C" int sm_plan_geometry(const sm_plan *plan, sm_geometry *out)
+{
+    return sm_plan_geometry_sized(plan, out, sizeof(sm_geometry));
 }
 
 extern "C" size_t sm_plan_workspace_bytes(const sm_plan *plan)

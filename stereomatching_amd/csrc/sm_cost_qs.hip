@@ -72,7 +72,13 @@ __global__ __launch_bounds__(64, 2) void k_sad_qs(const u8 *__restrict__ left, c
     constexpr bool SPLIT = N * N * 255 >= 65536;                     // two packed sums per shift
     constexpr int GL = SPLIT ? 3 : NG;                               // column groups of the first accumulator
     static_assert(RB == 1 || RB == 3, "odd windows");
-    static_assert(4 * GL * N * 255 < 65536 && (N - 4 * GL) * N * 255 < 65536, "each packed sum must fit 16 bits");
+    // What must fit 16 bits is each packed sum BETWEEN slides (n rows).  During a slide the entering row is added before
+    // the leaving one comes off, so a field holds up to n + 1 rows for an instant (21 x 21: 12 * 22 * 255 = 67 320) and
+    // may wrap -- which is exact: v_qsad_pk_u16_u8 and v_pk_sub_u16 work modulo 2^16 PER FIELD, without carry into the
+    // neighbouring field and without saturation (tools/ubench_sad.hip checks the wrap against a host model, lane 9),
+    // and the difference of the two is below 2^16 again.  A port to a saturating or carry-propagating form must take the
+    // leaving row off first.
+    static_assert(4 * GL * N * 255 < 65536 && (N - 4 * GL) * N * 255 < 65536, "each packed sum must fit 16 bits between slides");
     static_assert(!SPLIT || NG > GL, "the split needs groups on both sides");
     constexpr int KS = SPLIT ? 8 : 16;                               // bits of the shift in a key
     // "nothing yet": above every real key of a chunk (a real sum is below 2^16 / 2^17) and far enough from 2^32

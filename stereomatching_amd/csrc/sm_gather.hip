@@ -37,18 +37,28 @@ struct RcclApi {
 };
 
 RcclApi g_rccl;
+std::mutex g_once;                          // (communicators may be created from several host threads)
+char g_path[1024];                          // sm_comm_set_rccl_library: tried before the default names
+// A library that exports the symbol sm_rccl_host_stand_in declares itself a HOST stand-in for RCCL (tests/rccl_stub.c:
+// ranks are records, Send / Recv are memcpy at ncclGroupEnd): its communicators are driven with host buffers and no
+// device is touched -- the grouped point-to-point logic below can then run where there is one GPU, or none.
+bool g_host_stand_in;
 
 int load_rccl()
 {
-    static std::mutex once;                 // (communicators may be created from several host threads)
-    std::lock_guard<std::mutex> lock(once);
+    std::lock_guard<std::mutex> lock(g_once);
     if (g_rccl.handle) return SM_OK;
     void *h = nullptr;
+    if (g_path[0]) {
+        h = dlopen(g_path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return sm_fail(SM_ERR_HIP, "sm_comm_create: cannot load %s (%s)", g_path, dlerror());
+    }
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (h) break;
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     }
     if (!h) return sm_fail(SM_ERR_HIP, "sm_comm_create: cannot load librccl.so (%s)", dlerror());
+    g_host_stand_in = dlsym(h, "sm_rccl_host_stand_in") != nullptr;
     RcclApi a;
     a.handle = h;
 #define SM_SYM(field, sym)                                                         \
@@ -82,13 +92,24 @@ struct sm_comm {
             return sm_fail(SM_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(r_));  \
     } while (0)
 
+extern "C" int sm_comm_set_rccl_library(const char *path)
+{
+    std::lock_guard<std::mutex> lock(g_once);
+    if (g_rccl.handle) return sm_fail(SM_ERR_ARG, "sm_comm_set_rccl_library: the RCCL library is loaded already");
+    if (path && strlen(path) >= sizeof g_path) return sm_fail(SM_ERR_ARG, "sm_comm_set_rccl_library: path too long");
+    strcpy(g_path, path ? path : "");
+    return SM_OK;
+}
+
 extern "C" int sm_comm_create(const int *devices, int n, sm_comm **out)
 {
     if (!out) return sm_fail(SM_ERR_ARG, "sm_comm_create: out is NULL");
     *out = nullptr;
     if (!devices || n < 1 || n > 64) return sm_fail(SM_ERR_ARG, "sm_comm_create: need 1..64 devices");
-    int visible = 0;
-    SM_HIP(hipGetDeviceCount(&visible));
+    const int rc = load_rccl();             // (first: whether devices are looked at at all depends on the library)
+    if (rc) return rc;
+    int visible = n;
+    if (!g_host_stand_in) SM_HIP(hipGetDeviceCount(&visible));
     for (int i = 0; i < n; i++) {
         if (devices[i] < 0 || devices[i] >= visible)
             return sm_fail(SM_ERR_ARG, "sm_comm_create: device %d is not one of the %d visible", devices[i], visible);
@@ -96,8 +117,6 @@ extern "C" int sm_comm_create(const int *devices, int n, sm_comm **out)
             if (devices[j] == devices[i])     // RCCL refuses two ranks on one device; say so before it does
                 return sm_fail(SM_ERR_ARG, "sm_comm_create: device %d is listed twice (one rank per device)", devices[i]);
     }
-    const int rc = load_rccl();
-    if (rc) return rc;
     sm_comm *c = (sm_comm *)calloc(1, sizeof *c);
     if (c) {
         c->devices = (int *)malloc(sizeof(int) * n);
@@ -161,9 +180,12 @@ extern "C" int sm_gather_maps(sm_comm *comm, void *const *d_src, const size_t *b
     if (total && !d_dst) return sm_fail(SM_ERR_ARG, "sm_gather_maps: d_dst is NULL");
     // the root's own share: a copy on its own device, ordered on its stream
     if (bytes[0] && d_src[0] != d_dst) {
-        SM_HIP(hipSetDevice(comm->devices[0]));
-        SM_HIP(hipMemcpyAsync(d_dst, d_src[0], bytes[0], hipMemcpyDeviceToDevice,
-                              streams ? (hipStream_t)streams[0] : nullptr));
+        if (g_host_stand_in) memcpy(d_dst, d_src[0], bytes[0]);
+        else {
+            SM_HIP(hipSetDevice(comm->devices[0]));
+            SM_HIP(hipMemcpyAsync(d_dst, d_src[0], bytes[0], hipMemcpyDeviceToDevice,
+                                  streams ? (hipStream_t)streams[0] : nullptr));
+        }
     }
     if (comm->n == 1) return SM_OK;
     // every other rank SENDS exactly its own maps, the root receives them back to back in rank order:

@@ -77,7 +77,7 @@ class StereoPlan:
     def geometry(self) -> dict:
         """The kernel variant and tiling the plan selected (sm_plan_geometry)."""
         g = capi.Geometry()
-        check(lib.sm_plan_geometry(self._h, C.byref(g)))
+        check(lib.sm_plan_geometry_sized(self._h, C.byref(g), C.sizeof(g)))
         return {n: getattr(g, n) for n, _ in capi.Geometry._fields_}
 
     def valu_model(self, pairs: int = 1, want_best: bool = False):

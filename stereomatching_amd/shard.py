@@ -20,19 +20,38 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", 1)))
 
 
-def init(backend: str | None = None, force: bool = False):
+class InitError(RuntimeError):
+    """this rank could not join the job (no such device, rendezvous or communicator start-up failed or timed out)"""
+
+
+def init(backend: str | None = None, force: bool = False, timeout_s: float = 120.0):
     """Join the job described by the torchrun environment.  With the nccl (= RCCL) backend
     the rank's GPU is selected BEFORE the process group exists: every collective, the
     object broadcast included, runs on the current device, and two ranks on one device
-    is an RCCL error.  `force` creates the group even for a single rank (self-tests)."""
+    is an RCCL error.  `force` creates the group even for a single rank (self-tests).
+    Fails FAST and by name (InitError) instead of hanging: a rank whose device does not exist says so before the
+    rendezvous, the rendezvous and every later collective give up after `timeout_s`."""
+    import datetime
     rank, local_rank, world = env_world()
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+            n_dev = torch.cuda.device_count()
+            if local_rank >= n_dev:
+                raise InitError(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) are visible "
+                                f"(one process per GPU: --gpus / --nproc-per-node must not exceed the node's GPUs)")
+            try:
+                torch.cuda.set_device(local_rank)
+            except Exception as exc:          # noqa: BLE001
+                raise InitError(f"rank {rank}: cannot select GPU {local_rank}: {exc}") from exc
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=timeout_s))
+        except Exception as exc:              # noqa: BLE001
+            raise InitError(f"rank {rank}: {backend} process group of {world} rank(s) did not come up within "
+                            f"{timeout_s:.0f} s ({type(exc).__name__}: {exc})") from exc
     return rank, local_rank, world
 
 

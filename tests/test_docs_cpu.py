@@ -58,3 +58,20 @@ def test_cost_profile_names_kernels_that_exist():
     missing = [f for f in set(re.findall(r"`(?:…/)?((?:ab|pmc|ds_choice|write_size|cost)_[A-Za-z0-9_]+\.(?:txt|json))`", text))
                if not (ROOT / "profiles" / "r04" / f).exists() and not (ROOT / "profiles" / "r03" / f).exists()]
     assert not missing, missing
+
+
+def test_integration_lists_the_translation_units_that_are_built():
+    """INTEGRATION.md's account of the library (how many translation units, which) is what build.py and the
+    Makefile compile (round-4 review: the text said ten, the build had thirteen)"""
+    sys.path.insert(0, str(ROOT))
+    from stereomatching_amd import build
+    text = (ROOT / "INTEGRATION.md").read_text()
+    para = text[text.index("The library itself is"):]
+    para = para[:para.index("each compiled with")]
+    named = set(re.findall(r"`(sm_[a-z_0-9]+\.hip)`", para))
+    assert named == set(build.SOURCES), (sorted(named ^ set(build.SOURCES)))
+    words = {10: "ten", 11: "eleven", 12: "twelve", 13: "thirteen", 14: "fourteen", 15: "fifteen", 16: "sixteen"}
+    assert f"is {words[len(build.SOURCES)]} translation units" in para
+    mk = (ROOT / "Makefile").read_text()
+    kernels = re.search(r"^KERNELS := (.*)$", mk, re.M).group(1).split()
+    assert {k + ".hip" for k in kernels} == set(build.SOURCES)

@@ -643,6 +643,25 @@ def test_pipelined_runs_and_kernel_timing(hip):
     plan.close()
 
 
+def test_geometry_of_a_caller_compiled_against_an_older_header(hip):
+    """sm_plan_geometry_sized writes no more than the caller's struct holds (sm_geometry grows at its end from round to
+    round: ADVICE r04), and zeroes what a struct newer than the library has beyond it"""
+    import ctypes as C
+    lib, check = hip.capi.lib, hip.capi.check
+    plan = hip.StereoPlan(320, 200, 64, 7)
+    full = plan.geometry()
+    names = [n for n, _ in hip.capi.Geometry._fields_]
+    buf = (C.c_int * 40)(*([-7] * 40))
+    ptr = C.cast(buf, C.POINTER(hip.capi.Geometry))
+    check(lib.sm_plan_geometry_sized(plan._h, ptr, 8 * 4))              # an old struct of 8 fields
+    assert [buf[i] for i in range(8)] == [full[n] for n in names[:8]] and all(buf[i] == -7 for i in range(8, 40))
+    check(lib.sm_plan_geometry_sized(plan._h, ptr, 30 * 4))             # a newer one of 30
+    assert [buf[i] for i in range(len(names))] == [full[n] for n in names]
+    assert all(buf[i] == 0 for i in range(len(names), 30)) and all(buf[i] == -7 for i in range(30, 40))
+    assert lib.sm_plan_geometry_sized(plan._h, ptr, 2) == hip.capi.SM_ERR_ARG
+    plan.close()
+
+
 def test_runs_captured_into_a_graph(hip):
     """sm_run inside a stream capture (torch.cuda.graph; include/stereo_hip.h "STREAM CAPTURE"): a plain plan and a
     PIPELINED one -- whose lanes must leave and rejoin the capturing stream by events recorded inside the capture; round 4's
