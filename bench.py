@@ -90,6 +90,10 @@ def parse(argv=None):
                          "measured +1.4 %% at C3, profiles/r03/ab_pipelined_lanes.txt).  Off by default: a step is "
                          "then no longer one serial pass, and the per-launch kernel time is that of launches "
                          "sharing the chip")
+    ap.add_argument("--serial", action="store_true",
+                    help="issue every step with plain sm_run (strict stream order) instead of sm_run_after, whose only "
+                         "input dependency is an event (none here: the pairs are resident) and which lets the plan overlap "
+                         "consecutive steps on its two lanes where a match launch cannot fill the chip twice over")
     ap.add_argument("--c4", action="store_true",
                     help="add the `c4` object (64 x 1080p pairs sharded over the ranks + the collection of the maps "
                          "on rank 0) also at N = 1; at N > 1 it is always there")
@@ -366,10 +370,14 @@ def small_config_leg(dev, cfg, threshold, use_graph):
     web = torch.zeros((resident, h, w), dtype=torch.int32, device=dev)
     lib, check = pipeline.capi.lib, pipeline.capi.check
 
-    def step(k, st, out=None):
+    def step(k, st, out=None, serial=False):
         o = web if out is None else out
-        check(lib.sm_run(plan._h, C.c_void_p(L[k].data_ptr()), C.c_void_p(R[k].data_ptr()), threshold, 1,
-                         C.c_void_p(o[k].data_ptr()), C.c_void_p(0), st))
+        if serial:
+            check(lib.sm_run(plan._h, C.c_void_p(L[k].data_ptr()), C.c_void_p(R[k].data_ptr()), threshold, 1,
+                             C.c_void_p(o[k].data_ptr()), C.c_void_p(0), st))
+        else:
+            check(lib.sm_run_after(plan._h, C.c_void_p(L[k].data_ptr()), C.c_void_p(R[k].data_ptr()), threshold, 1,
+                                   C.c_void_p(o[k].data_ptr()), 0, C.c_void_p(0), st, C.c_void_p(0)))
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for k in range(resident):
         step(k, stream)
@@ -405,18 +413,18 @@ def small_config_leg(dev, cfg, threshold, use_graph):
     torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) / steps * 1e3
     timed = web.clone()
-    # host-launched, step by step
+    # host-launched, step by step, plain sm_run
     for i in range(16):
-        step(i % resident, stream)
+        step(i % resident, stream, serial=True)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(steps):
-        step(i % resident, stream)
+        step(i % resident, stream, serial=True)
     torch.cuda.synchronize(dev)
     ms_host = (time.perf_counter() - t0) / steps * 1e3
     chk = torch.empty_like(web)
     for k in range(resident):
-        step(k, stream, chk)
+        step(k, stream, chk, serial=True)
     torch.cuda.synchronize(dev)
     vy0, vrows = h // 2, 32
     ow, _, _ = oracle_band(prs[0][0], prs[0][1], vy0, vrows, d, sw, mode, threshold)
@@ -426,7 +434,8 @@ def small_config_leg(dev, cfg, threshold, use_graph):
     return {"workload": f"{cfg}: {w}x{h} pair, {d} shifts, {sw}x{sw} window, {mode} border, 1 pair/step; edges + fused "
                         "match/aggregate/WTA -> web, inputs resident",
             "ms_per_step": round(ms, 4), "value": round(float(w) * h * d / ms / 1e3, 1), "unit": "Mpixel-disparities/s",
-            "steps": steps, "timed_steps": f"{gsteps} steps per HIP graph" if graph is not None else (note or "launched from the host"),
+            "steps": steps, "timed_steps": (f"{gsteps} steps per HIP graph" if graph is not None else (note or "launched from the host")) +
+                                           "; sm_run_after: consecutive steps overlap on the plan's two lanes",
             "host_launched_ms_per_step": round(ms_host, 4), "kernel": text,
             "verified": ok,
             "verified_how": f"the {resident} maps the timed steps left equal host-launched runs; rows {vy0} .. {vy0 + vrows - 1} "
@@ -544,6 +553,10 @@ def timing_stride(steps: int) -> int:
 
 def main():
     args = parse()
+    if not args.graph and not args.pipeline:
+        # launched from the host, step by step, the overlap costs more host calls (an event wait and a record per step)
+        # than it wins (C3: 0.105 against 0.094 ms per step): host-launched steps are issued in plain stream order
+        args.serial = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
@@ -691,10 +704,17 @@ def main():
     plan.set_pipelined(args.pipeline)
     plan.prepare_threshold(args.threshold)     # set-up next to the allocations
 
-    def step(st=None):
+    def step(st=None, serial=False):
         k = turn[0]
         turn[0] = k + 1 if k + 1 < resident else 0
-        check(lib.sm_run(plan._h, p_l[k], p_r[k], args.threshold, pairs, p_web[k], p_best[k], st or stream))
+        if serial or args.serial:
+            check(lib.sm_run(plan._h, p_l[k], p_r[k], args.threshold, pairs, p_web[k], p_best[k], st or stream))
+        else:       # inputs resident: no event to wait for; consecutive steps may overlap (include/stereo_hip.h)
+            check(lib.sm_run_after(plan._h, p_l[k], p_r[k], args.threshold, pairs, p_web[k], 0, p_best[k], st or stream,
+                                   C.c_void_p(0)))
+    geo0 = plan.geometry()
+    overlapped = bool(args.pipeline) or (not args.serial and
+                                         geo0["tiles_x"] * geo0["tiles_y"] * pairs * max(1, geo0["threads"] // 64) < 2048)
 
     # --graph: `gsteps` consecutive steps (a whole number of turns over the resident batches) captured once
     graph, gsteps, graph_note = None, 0, None
@@ -781,8 +801,9 @@ def main():
         # the kernel time of a --graph run is sampled in a pass of single steps right behind the timed region)
         n_samples = 16
         plan.time_kernels(n_samples, 1)
+        plan.set_pipelined(False)
         for _ in range(n_samples):
-            step()
+            step(serial=True)           # (a launch that has the chip to itself: what the roofline prices)
         torch.cuda.synchronize(dev)
     kernel_ms, n_timed = plan.kernel_ms()
     assert n_timed == n_samples, (n_timed, n_samples)
@@ -802,19 +823,20 @@ def main():
     torch.cuda.synchronize(dev)
     same_as_host_launched = bool(torch.equal(web_timed, chk))
     host_launched = None
-    if graph is not None or args.pipeline:
+    if graph is not None or overlapped:
         # ... and the rate of the plain host-launched path beside the default's (both in the line)
         turn[0] = 0
         n_hl = max(resident, min(args.steps, 200))
         for _ in range(WARMUP_BURST):
-            step()
+            step(serial=True)
         torch.cuda.synchronize(dev)
         h0 = time.perf_counter()
         for _ in range(n_hl):
-            step()
+            step(serial=True)
         torch.cuda.synchronize(dev)
         host_launched = {"ms_per_step": round((time.perf_counter() - h0) / n_hl * 1e3, 4), "steps": n_hl,
-                         "note": "every step launched from the host, no overlap; this rank only, outside the timed region"}
+                         "note": "plain sm_run, every step launched from the host in stream order; this rank only, outside the "
+                                 "timed region"}
     # (b) a full-width band of the first map against the CPU oracle (rank 0, below: the cpu_baseline leg's own band)
     verify_rows = min(args.cpu_rows, 48) if (args.no_cpu_baseline or world > 1) else args.cpu_rows
     verify_rows = max(1, min(verify_rows, h - 2 * (sw // 2 + 1)))
@@ -931,11 +953,12 @@ def main():
                         f"{pairs} pair(s)/GPU/step; edges + fused match/aggregate/WTA -> web",
             "kernel": plan_text,
             "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
-            "pipelined": args.pipeline,
+            "pipelined": overlapped,
             "graph": f"{gsteps} steps per HIP graph" if graph is not None else (graph_note or False),
         },
         "timed_steps": ("replayed from HIP graphs" if graph is not None else "launched from the host") +
-                       ("; consecutive steps overlapped on the plan's two lanes" if args.pipeline else ""),
+                       ("; consecutive steps overlapped on the plan's two lanes (sm_run_after: a step's only input "
+                        "dependency is its resident pair)" if overlapped else "; strict stream order"),
         "graph_capture": "ok" if graph is not None else ("not asked for" if not args.graph or args.steps < resident
                                                          else (graph_note or "failed")),
         "roofline": roof,

@@ -293,6 +293,20 @@ int sm_run(sm_plan *plan, const uint8_t *d_gray_left,
            const uint8_t *d_gray_right, double threshold, int pairs,
            int32_t *d_web, int32_t *d_best, void *stream);
 
+/* sm_run_typed whose only INPUT dependency is an event -- instead of "everything enqueued on `stream` before the call"
+ * (the reference synchronises on its uploads before every pair: src/stereo.cu:402-403).  `inputs_ready_event` (a
+ * hipEvent_t, e.g. recorded behind the upload of this pair on a copy stream; NULL = the images are complete now) is all
+ * the call waits for besides earlier calls on the same plan that share something with it (result maps, the threshold
+ * tables, the narrow staging map: put in order by the library); work enqueued on `stream` AFTER the call sees the
+ * results.  That freedom is what lets consecutive calls overlap, and the plan takes it by itself: a match launch of
+ * fewer than 2 x 1024 waves (a lone pair up to 4K: it cannot fill the chip twice over, and the next call's edge
+ * detection and first waves fit beside its tail) runs on the plan's two internal lanes as under
+ * sm_plan_set_pipelined(1); larger launches run in `stream` order behind the event.  Give consecutive calls their
+ * own result maps.  Inside a stream capture the event must be one recorded in the same capture.                    */
+int sm_run_after(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
+                 double threshold, int pairs, void *d_web, int web_type, int32_t *d_best,
+                 void *stream, void *inputs_ready_event);
+
 /* STREAM CAPTURE (hipStreamBeginCapture on `stream`, torch.cuda.graph): sm_run, sm_find_edges, sm_match_wta and
  * sm_cost_wta may be recorded into a graph and replayed; a plan is single-stream, so do not run it eagerly while a
  * graph that holds its launches is in flight.  What cannot be captured returns SM_ERR_ARG with a message that names

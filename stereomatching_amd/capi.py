@@ -100,6 +100,7 @@ _SIGNATURES = {
     "sm_match_wta": (_int, [_vp, _int, _vp, _vp, _vp]),
     "sm_match_wta_typed": (_int, [_vp, _int, _vp, _int, _vp, _vp]),
     "sm_run_typed": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _int, _vp, _vp]),
+    "sm_run_after": (_int, [_vp, _vp, _vp, _dbl, _int, _vp, _int, _vp, _vp, _vp]),
     "sm_plan_set_pipelined": (_int, [_vp, _int]),
     "sm_plan_prepare_threshold": (_int, [_vp, C.c_double, _vp]),
     "sm_plan_time_kernels": (_int, [_vp, _int]),

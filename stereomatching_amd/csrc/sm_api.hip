@@ -1351,6 +1351,10 @@ extern "C" int sm_run(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *
     return sm_run_typed(plan, d_gray_left, d_gray_right, threshold, pairs, d_web, SM_WEB_I32, d_best, stream);
 }
 
+static int run_on_lanes(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
+                        double threshold, int pairs, void *d_web, int web_type, int32_t *d_best,
+                        void *stream, hipEvent_t inputs_ready);
+
 extern "C" int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
                             double threshold, int pairs, void *d_web, int web_type, int32_t *d_best,
                             void *stream)
@@ -1359,6 +1363,38 @@ extern "C" int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uin
         SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, stream));
         return sm_match_wta_typed(plan, pairs, d_web, web_type, d_best, stream);
     }
+    return run_on_lanes(plan, d_gray_left, d_gray_right, threshold, pairs, d_web, web_type, d_best, stream, nullptr);
+}
+
+// sm_run whose ONLY input dependency is an event (DESIGN.md 9.4 of round 4; replaces the synchronous upload in front of
+// every call, src/stereo.cu:402-403): the call is free to overlap with the one before it, and the plan takes the two
+// lanes by itself where that pays -- a match launch that does not fill the chip twice over (fewer than 2 x 1024 waves:
+// a lone pair up to 4K), or a plan set pipelined.
+extern "C" int sm_run_after(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
+                            double threshold, int pairs, void *d_web, int web_type, int32_t *d_best,
+                            void *stream, void *inputs_ready_event)
+{
+    SM_TRY(check_plan_pairs(plan, pairs, "sm_run_after"));
+    const MatchGeom &g = plan->g;
+    const long long waves = (long long)g.tiles_x * g.tiles_y * pairs * ((g.threads + 63) / 64);
+    if (!plan->pipelined && waves >= 2 * 1024) {
+        SM_TRY(use_device(plan->device));
+        if (inputs_ready_event) SM_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)inputs_ready_event, 0));
+        SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, stream));
+        return sm_match_wta_typed(plan, pairs, d_web, web_type, d_best, stream);
+    }
+    const int was = plan->pipelined;
+    if (!was) plan->pipelined = 1;          // (the match launch records the call's release event when the plan is pipelined)
+    const int rc = run_on_lanes(plan, d_gray_left, d_gray_right, threshold, pairs, d_web, web_type, d_best, stream,
+                                (hipEvent_t)inputs_ready_event);
+    plan->pipelined = was;
+    return rc;
+}
+
+static int run_on_lanes(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
+                        double threshold, int pairs, void *d_web, int web_type, int32_t *d_best,
+                        void *stream, hipEvent_t inputs_ready)
+{
     // pipelined: call q runs on one of two lanes (internal streams, alternating): its edge detection
     // into the lane's own ext buffer, then its match launch, in stream order.  Nothing orders call q
     // against call q - 1 on the other lane, so the edges of call q run beside the match of call q - 1,
@@ -1410,6 +1446,7 @@ extern "C" int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uin
             SM_HIP(hipEventRecord(plan->ev_fork[b], user));
         }
         SM_HIP(hipStreamWaitEvent(lane, plan->ev_fork[b], 0));
+        if (inputs_ready) SM_HIP(hipStreamWaitEvent(lane, inputs_ready, 0));     // (an event of this capture, or the call fails)
         if (shared && !first) SM_HIP(hipStreamWaitEvent(lane, plan->ev_free[(q - 1) & 3], 0));
         plan->seq = q;
         plan->cur = b;
@@ -1434,6 +1471,7 @@ extern "C" int sm_run_typed(sm_plan *plan, const uint8_t *d_gray_left, const uin
         if (plan->unfenced) SM_HIP(hipStreamWaitEvent(plan->lane[b ^ 1], plan->ev_inputs, 0));
         plan->unfenced = 0;
     }
+    if (inputs_ready) SM_HIP(hipStreamWaitEvent(lane, inputs_ready, 0));
     if (plan->ev_free_set[(q - 3) & 3]) SM_HIP(hipStreamWaitEvent(lane, plan->ev_free[(q - 3) & 3], 0));
     if (shared && plan->ev_free_set[(q - 1) & 3]) SM_HIP(hipStreamWaitEvent(lane, plan->ev_free[(q - 1) & 3], 0));
     plan->seq = q;

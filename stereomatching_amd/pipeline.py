@@ -192,6 +192,23 @@ class StereoPlan:
                                WEB_TYPES[web_dtype], _ptr(best if want_best else None), self._stream()))
         return web, (best if want_best else None)
 
+    def run_after(self, left, right, threshold=DEFAULT_THRESHOLD, inputs_ready=None, want_best=False, web=None,
+                  best=None, web_dtype=torch.int32):
+        """run() whose only input dependency is `inputs_ready` (a torch.cuda.Event or None = complete now): consecutive
+        calls may overlap, and on launches that cannot fill the chip twice over the plan lets them (sm_run_after)."""
+        left = self._images(left, torch.uint8, "left")
+        right = self._images(right, torch.uint8, "right")
+        pairs = left.shape[0]
+        web = self._out(web, pairs, "web", web_dtype)
+        best = self._out(best, pairs, "best") if want_best else None
+        if web_dtype != torch.int32 and not getattr(self, "_narrow_ready", False) and \
+                not torch.cuda.is_current_stream_capturing():
+            self.reserve_narrow()
+        ev = C.c_void_p(inputs_ready.cuda_event) if inputs_ready is not None else C.c_void_p(0)
+        check(lib.sm_run_after(self._h, _ptr(left), _ptr(right), float(threshold), pairs, _ptr(web),
+                               WEB_TYPES[web_dtype], _ptr(best if want_best else None), self._stream(), ev))
+        return web, (best if want_best else None)
+
     def cost_wta(self, left, right, cost="sad", want_best=True, web=None, best=None):
         """SAD / SSD cost mode on the uint8 images (parity unpinned: the reference has no
         such mode) -> (web, best): arg-min over the shifts, first shift wins."""

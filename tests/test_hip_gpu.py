@@ -643,6 +643,83 @@ def test_pipelined_runs_and_kernel_timing(hip):
     plan.close()
 
 
+def test_run_after_an_input_ready_event(hip):
+    """sm_run_after: the call's only input dependency is an event.  The uploads of six pairs go out on a COPY stream
+    into six buffer pairs, an event behind each; the calls go out on the compute stream at once, without any other
+    ordering -- every map must be its pair's (a lane that did not wait shows up as garbage or a neighbour's map).
+    Small launches (this one: a few dozen waves) take the plan's two lanes by themselves; a launch of >= 2048 waves
+    (a batch of 4 x 1080p... here: forced by a tall batch) stays in stream order.  Also inside a graph."""
+    w, h, d, sw = 320, 200, 64, 7
+    pairs = [make_pair(w, h, d, seed=300 + i) for i in range(6)]
+    want = [oracle.pipeline(l, r, 0.15, d, sw, step3=False)["web-1"] for l, r in pairs]
+    plan = hip.StereoPlan(w, h, d, sw)
+    plan.prepare_threshold(0.15)
+    hl = [torch.from_numpy(l).pin_memory() for l, _ in pairs]
+    hr = [torch.from_numpy(r).pin_memory() for _, r in pairs]
+    dl = [torch.zeros((h, w), dtype=torch.uint8, device="cuda") for _ in pairs]
+    dr = [torch.zeros((h, w), dtype=torch.uint8, device="cuda") for _ in pairs]
+    webs = [torch.zeros((1, h, w), dtype=torch.int32, device="cuda") for _ in pairs]
+    copy = torch.cuda.Stream()
+    for rep in range(3):
+        for o in webs:
+            o.zero_()
+        for a, b in zip(dl, dr):
+            a.zero_(); b.zero_()
+        torch.cuda.synchronize()
+        evs = []
+        with torch.cuda.stream(copy):
+            for i in range(len(pairs)):
+                dl[i].copy_(hl[i], non_blocking=True)
+                dr[i].copy_(hr[i], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy)
+                evs.append(ev)
+        for i in range(len(pairs)):
+            plan.run_after(dl[i], dr[i], 0.15, inputs_ready=evs[i], web=webs[i])
+        torch.cuda.synchronize()
+        for i in range(len(pairs)):
+            assert np.array_equal(host(webs[i])[0], want[i]), (rep, i)
+    # mixed with plain runs, a changing threshold and ONE shared map: still ordered
+    one = torch.zeros((1, h, w), dtype=torch.int32, device="cuda")
+    for i in range(len(pairs)):
+        plan.run_after(dl[i], dr[i], 0.15, web=one)
+        if i % 2:
+            plan.run(dl[i], dr[i], 0.15, web=one)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(one)[0], want[-1])
+    # inside a graph: the overlap is kept (the plan forks and joins its lanes by the capture's own events)
+    g = torch.cuda.CUDAGraph()
+    for o in webs:
+        o.zero_()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        for i in range(len(pairs)):
+            plan.run_after(dl[i], dr[i], 0.15, web=webs[i])
+    g.replay()
+    torch.cuda.synchronize()
+    for i in range(len(pairs)):
+        assert np.array_equal(host(webs[i])[0], want[i]), i
+    plan.close()
+    # a launch that fills the chip more than twice over stays on the caller's stream, behind the event
+    plan = hip.StereoPlan(1920, 1080, 64, 7, max_pairs=4)
+    big = [make_pair(1920, 1080, 64, seed=310 + i) for i in range(4)]
+    L = torch.from_numpy(np.stack([p[0] for p in big])).pin_memory()
+    R = torch.from_numpy(np.stack([p[1] for p in big])).pin_memory()
+    gl, gr = torch.zeros_like(L, device="cuda"), torch.zeros_like(R, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(copy):
+        gl.copy_(L, non_blocking=True)
+        gr.copy_(R, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(copy)
+    web, _ = plan.run_after(gl, gr, 0.15, inputs_ready=ev)
+    torch.cuda.synchronize()
+    ref, _ = plan.run(gl, gr, 0.15)
+    assert torch.equal(web, ref)
+    o = oracle.pipeline(big[2][0], big[2][1], 0.15, 64, 7, step3=False)
+    assert np.array_equal(host(web)[2], o["web-1"])
+    plan.close()
+
+
 def test_geometry_of_a_caller_compiled_against_an_older_header(hip):
     """sm_plan_geometry_sized writes no more than the caller's struct holds (sm_geometry grows at its end from round to
     round: ADVICE r04), and zeroes what a struct newer than the library has beyond it"""
