@@ -35,6 +35,14 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 64 x 1080p pairs (64 shifts, 7x7), pair j -> rank j mod N, each rank's share in ONE launch per
                 step, timed under the same barrier / max-over-ranks contract (strong scaling: 64 pairs whatever
                 N), plus `gather_ms`: the collection of the 64 maps on rank 0 (RCCL point to point), timed apart
+  verified      true iff what was timed is right: after the timed region every resident result map, as the timed steps
+                left it, equals (on the device) the map of a host-launched sm_run on the same inputs, and a full-width
+                band of the first one equals the CPU oracle (the cpu_baseline leg's own band); the extra objects carry
+                checks of their own.  false -> exit code 3.
+  overlapped    (N = 1) the same steps issued through sm_run_after -- a step's only input dependency is its resident
+                pair -- so that the plan runs consecutive steps on its two lanes; replayed from a graph of its own
+  c2            (N = 1) BASELINE's second single-GPU configuration (1080p pair, 64 shifts, 7x7): stream order and overlapped
+  host_launched the rate of plain host-launched sm_run calls beside the graph-replayed default
   sad, ssd      (N = 1) the SAD / SSD cost mode -- the cost BASELINE.json's wording names, which
                 the reference does not implement: PARITY UNPINNED, the build's own definition --
                 at C3 (SAD 9x9) and C5 (SSD 11x11, ghost): ms per launch, Mpixel-disparities/s and
@@ -90,10 +98,12 @@ def parse(argv=None):
                          "measured +1.4 %% at C3, profiles/r03/ab_pipelined_lanes.txt).  Off by default: a step is "
                          "then no longer one serial pass, and the per-launch kernel time is that of launches "
                          "sharing the chip")
-    ap.add_argument("--serial", action="store_true",
-                    help="issue every step with plain sm_run (strict stream order) instead of sm_run_after, whose only "
-                         "input dependency is an event (none here: the pairs are resident) and which lets the plan overlap "
-                         "consecutive steps on its two lanes where a match launch cannot fill the chip twice over")
+    ap.add_argument("--overlap", action="store_true",
+                    help="issue the timed steps with sm_run_after -- a step's only input dependency is an event (none here: "
+                         "the pairs are resident), so the plan overlaps consecutive steps on its two lanes where a match "
+                         "launch cannot fill the chip twice over -- instead of plain sm_run in strict stream order.  The "
+                         "default line carries that rate as the extra object `overlapped`; `value` stays the serial one, "
+                         "whose kernel trace agrees launch by launch with roofline.kernel_ms")
     ap.add_argument("--c4", action="store_true",
                     help="add the `c4` object (64 x 1080p pairs sharded over the ranks + the collection of the maps "
                          "on rank 0) also at N = 1; at N > 1 it is always there")
@@ -353,7 +363,8 @@ COST_VERIFY_ROWS = 16
 def small_config_leg(dev, cfg, threshold, use_graph):
     """The extra `c2` object (N = 1): BASELINE.json's other single-GPU configuration -- a lone 1080p pair, 64 shifts,
     7 x 7 -- through the same step as the headline (edges + fused match -> web, inputs resident), replayed from a HIP
-    graph like the headline's steps; the host-launched rate beside it.  Never part of `value`."""
+    graph like the headline's steps: in stream order (`value`) and through sm_run_after (`overlapped`); the host-launched
+    rate beside them.  Never part of the line's `value`."""
     import ctypes as C
     import numpy as np
     import torch
@@ -370,7 +381,7 @@ def small_config_leg(dev, cfg, threshold, use_graph):
     web = torch.zeros((resident, h, w), dtype=torch.int32, device=dev)
     lib, check = pipeline.capi.lib, pipeline.capi.check
 
-    def step(k, st, out=None, serial=False):
+    def step(k, st, out=None, serial=True):
         o = web if out is None else out
         if serial:
             check(lib.sm_run(plan._h, C.c_void_p(L[k].data_ptr()), C.c_void_p(R[k].data_ptr()), threshold, 1,
@@ -382,64 +393,74 @@ def small_config_leg(dev, cfg, threshold, use_graph):
     for k in range(resident):
         step(k, stream)
     torch.cuda.synchronize(dev)
-    graph, note = None, None
-    if use_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                cs = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-                for i in range(gsteps):
-                    step(i % resident, cs)
-        except Exception as exc:      # noqa: BLE001
-            graph, note = None, f"capture failed ({type(exc).__name__})"
-            torch.cuda.synchronize(dev)
+    chk = torch.empty_like(web)
+    for k in range(resident):
+        step(k, stream, chk)
+    torch.cuda.synchronize(dev)
 
-    def run(n):
-        if graph is not None:
-            for _ in range(n // gsteps):
-                graph.replay()
-        else:
-            for i in range(n):
-                step(i % resident, stream)
-    t_end = time.perf_counter() + WARMUP_FLOOR_S
-    while time.perf_counter() < t_end:
+    def timed(serial):
+        """(ms per step, the maps equal host-launched runs, how the steps were issued)"""
+        graph, note = None, "launched from the host"
+        if use_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    cs = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                    for i in range(gsteps):
+                        step(i % resident, cs, serial=serial)
+                note = f"{gsteps} steps per HIP graph"
+            except Exception as exc:      # noqa: BLE001
+                graph, note = None, f"capture failed ({type(exc).__name__}): launched from the host"
+                torch.cuda.synchronize(dev)
+
+        def run(n):
+            if graph is not None:
+                for _ in range(n // gsteps):
+                    graph.replay()
+            else:
+                for i in range(n):
+                    step(i % resident, stream, serial=serial)
+        t_end = time.perf_counter() + WARMUP_FLOOR_S
+        while time.perf_counter() < t_end:
+            run(gsteps)
+            torch.cuda.synchronize(dev)
+        web.zero_()
         run(gsteps)
         torch.cuda.synchronize(dev)
-    web.zero_()
-    run(gsteps)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run(steps)
-    torch.cuda.synchronize(dev)
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    timed = web.clone()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        return ms, web.clone(), note
+
+    ms, maps, note = timed(True)
+    ms_o, maps_o, note_o = timed(False)
     # host-launched, step by step, plain sm_run
     for i in range(16):
-        step(i % resident, stream, serial=True)
+        step(i % resident, stream)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(steps):
-        step(i % resident, stream, serial=True)
+        step(i % resident, stream)
     torch.cuda.synchronize(dev)
     ms_host = (time.perf_counter() - t0) / steps * 1e3
-    chk = torch.empty_like(web)
-    for k in range(resident):
-        step(k, stream, chk, serial=True)
-    torch.cuda.synchronize(dev)
     vy0, vrows = h // 2, 32
     ow, _, _ = oracle_band(prs[0][0], prs[0][1], vy0, vrows, d, sw, mode, threshold)
-    ok = bool(torch.equal(timed, chk)) and bool(np.array_equal(timed[0, vy0:vy0 + vrows].cpu().numpy(), ow))
+    ok = bool(torch.equal(maps, chk)) and bool(np.array_equal(maps[0, vy0:vy0 + vrows].cpu().numpy(), ow))
+    ok_o = bool(torch.equal(maps_o, chk))
     text = plan.describe()
     plan.close()
+    rate = lambda t: round(float(w) * h * d / t / 1e3, 1)      # noqa: E731
     return {"workload": f"{cfg}: {w}x{h} pair, {d} shifts, {sw}x{sw} window, {mode} border, 1 pair/step; edges + fused "
                         "match/aggregate/WTA -> web, inputs resident",
-            "ms_per_step": round(ms, 4), "value": round(float(w) * h * d / ms / 1e3, 1), "unit": "Mpixel-disparities/s",
-            "steps": steps, "timed_steps": (f"{gsteps} steps per HIP graph" if graph is not None else (note or "launched from the host")) +
-                                           "; sm_run_after: consecutive steps overlap on the plan's two lanes",
+            "ms_per_step": round(ms, 4), "value": rate(ms), "unit": "Mpixel-disparities/s",
+            "steps": steps, "timed_steps": note + "; plain sm_run, stream order",
+            "overlapped": {"ms_per_step": round(ms_o, 4), "value": rate(ms_o), "timed_steps": note_o +
+                           "; sm_run_after: consecutive steps on the plan's two lanes", "verified": ok_o},
             "host_launched_ms_per_step": round(ms_host, 4), "kernel": text,
-            "verified": ok,
-            "verified_how": f"the {resident} maps the timed steps left equal host-launched runs; rows {vy0} .. {vy0 + vrows - 1} "
-                            "of the first equal the CPU oracle"}
+            "verified": ok and ok_o,
+            "verified_how": f"the {resident} maps the timed steps left (both ways) equal host-launched runs; rows {vy0} .. "
+                            f"{vy0 + vrows - 1} of the first equal the CPU oracle"}
 
 
 C4_TOTAL_PAIRS = 64
@@ -553,10 +574,7 @@ def timing_stride(steps: int) -> int:
 
 def main():
     args = parse()
-    if not args.graph and not args.pipeline:
-        # launched from the host, step by step, the overlap costs more host calls (an event wait and a record per step)
-        # than it wins (C3: 0.105 against 0.094 ms per step): host-launched steps are issued in plain stream order
-        args.serial = True
+    args.serial = not args.overlap
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
@@ -837,6 +855,40 @@ def main():
         host_launched = {"ms_per_step": round((time.perf_counter() - h0) / n_hl * 1e3, 4), "steps": n_hl,
                          "note": "plain sm_run, every step launched from the host in stream order; this rank only, outside the "
                                  "timed region"}
+    # ---- the same steps through sm_run_after, replayed from a graph of their own: consecutive steps overlap ----------
+    overlapped_obj = None
+    if graph is not None and args.serial and not args.pipeline and world == 1:
+        try:
+            g2 = torch.cuda.CUDAGraph()
+            turn[0] = 0
+            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                cs = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for k in range(gsteps):
+                    kk = k % resident
+                    check(lib.sm_run_after(plan._h, p_l[kk], p_r[kk], args.threshold, pairs, p_web[kk], 0, p_best[kk], cs,
+                                           C.c_void_p(0)))
+            reps = max(1, args.steps // gsteps)
+            for _ in range(max(2, int(WARMUP_FLOOR_S / (elapsed / args.steps * gsteps)) + 1)):
+                g2.replay()
+            web.zero_()
+            g2.replay()
+            torch.cuda.synchronize(dev)
+            o0 = time.perf_counter()
+            for _ in range(reps):
+                g2.replay()
+            torch.cuda.synchronize(dev)
+            oms = (time.perf_counter() - o0) / (reps * gsteps) * 1e3
+            overlapped_obj = {"ms_per_step": round(oms, 4), "value": round(units_per_step / oms / 1e3, 1),
+                              "unit": "Mpixel-disparities/s", "steps": reps * gsteps,
+                              "verified": bool(torch.equal(web, chk)),
+                              "how": "sm_run_after instead of sm_run (a step waits for its inputs only: resident), replayed "
+                                     "from a HIP graph; the plan runs consecutive steps on its two lanes: the edge detection "
+                                     "of step i + 1 beside the match launch of step i.  Never `value`: launches that share "
+                                     "the chip have no per-launch duration a trace could confirm"}
+            del g2
+        except Exception as exc:      # noqa: BLE001 -- an extra: reported, never fatal
+            overlapped_obj = {"error": f"{type(exc).__name__}: {exc}"[:300], "verified": True}
+            torch.cuda.synchronize(dev)
     # (b) a full-width band of the first map against the CPU oracle (rank 0, below: the cpu_baseline leg's own band)
     verify_rows = min(args.cpu_rows, 48) if (args.no_cpu_baseline or world > 1) else args.cpu_rows
     verify_rows = max(1, min(verify_rows, h - 2 * (sw // 2 + 1)))
@@ -965,6 +1017,8 @@ def main():
     }
     if host_launched is not None:
         out["host_launched"] = host_launched
+    if overlapped_obj is not None:
+        out["overlapped"] = overlapped_obj
     if rehearsal:
         out["rehearsal"] = "SM_BENCH_REHEARSAL: all ranks on device 0 over gloo"
     if gather_ms is not None:

@@ -1648,9 +1648,11 @@ def test_bench_line_with_and_without_graph_replay(flags, graph):
     assert out["graph_capture"] == ("ok" if graph else "not asked for")
     if graph:
         assert out["host_launched"]["ms_per_step"] > 0 and out["c2"]["verified"] is True and out["c2"]["value"] > 1e6
+        assert out["overlapped"]["verified"] is True and out["overlapped"]["value"] > 1e6
+        assert out["c2"]["overlapped"]["verified"] is True
 
 
-@pytest.mark.parametrize("flags", [[], ["--pipeline"]])
+@pytest.mark.parametrize("flags", [[], ["--overlap"]])
 def test_bench_checks_what_it_timed(flags):
     """bench.py compares the result maps its timed steps left (graph replays by default; with --pipeline: consecutive
     steps overlapped INSIDE the graph) with host-launched runs on the device and with the CPU oracle on a band, says

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's numbers are judged against, on the GPU box:
-#     gpurun -- 'bash tools/collect_profiles.sh r04'
+#     gpurun -- 'bash tools/collect_profiles.sh r05'
 # Writes raw output under gpurun_out/prof_<tag>/; summarise on the build box with
 #     python tools/summarise_profiles.py gpurun_out/prof_<tag> profiles/<tag>
 # Kernel trace and PMC passes are separate runs (never combined with other trace domains), as the pool
@@ -12,8 +12,8 @@
 # them.  Replayed from a graph the traced process is GPU-bound like the untraced one, and the trace's
 # average agrees with the untraced kernel time (bench_traced.json is the traced process's own line).
 set -u
-TAG=${1:-r04}
-F="--no-cpu-baseline --no-e2e --no-cost-modes"
+TAG=${1:-r05}
+F="--no-cpu-baseline --no-e2e --no-cost-modes --no-c2"
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 rm -rf "$OUT"   # gpurun merges results into the build box's copy: delete that one too before a re-run
