@@ -55,7 +55,7 @@ __device__ __forceinline__ u32 sdot4(u32 a, u32 b, u32 acc) { return (u32)__buil
 constexpr int mfma_waves(int nb) { return nb <= MFMA_W4 ? 4 : nb <= MFMA_W3 ? 3 : 2; }
 
 template <int N, int NB>
-__global__ __launch_bounds__(64, mfma_waves(NB)) void k_ssd_mfma(const u8 *__restrict__ left, const u8 *__restrict__ right,
+__global__ __launch_bounds__(256, mfma_waves(NB)) void k_ssd_mfma(const u8 *__restrict__ left, const u8 *__restrict__ right,
                                                     i32 *__restrict__ web, i32 *__restrict__ best,
                                                     const SadGeom g)
 {
@@ -67,24 +67,28 @@ __global__ __launch_bounds__(64, mfma_waves(NB)) void k_ssd_mfma(const u8 *__res
     static_assert(NB >= 1 && NB <= 9, "D <= 256");
 
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    const int tid = threadIdx.x;
+    // Round 5: g.waves (1, 2 or 4) waves per workgroup, side by side, 32 pixels each, SHARE the staged rows: one right-image
+    // span of 32 (NB + waves - 1) positions instead of `waves` spans of 32 NB -- the LDS a wave needs per row falls (C5: 384 ->
+    // 224 bytes at two waves), the tile gets taller, the n - 1 warm-up rows weigh less, and the launch fetches its inputs
+    // half as often.  Every wave keeps a table of its own and never waits for its neighbours after the staging.
+    const int tid = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.z;
-    const int xw = blockIdx.x * 32, ty0 = blockIdx.y * g.tile_h;
+    const int xw = blockIdx.x * g.tw, ty0 = blockIdx.y * g.tile_h;
     const size_t img = (size_t)pair * g.w * g.h;
     const u8 *L = left + img, *R = right + img;
     const int lw = g.lrow >> 2, rw = g.rrow >> 2;
     u32 *sL = lds;                                                   // [nsr][lw]
     u32 *sR = sL + g.nsr * lw;                                       // [nsr][rw]
     // entry(u) = -(T(u) << 8) - (u & 255), T = RR minus twice the drift of the LR sums (see the step); 16-byte aligned
-    u32 *sT = sR + g.nsr * rw + g.tbl_pad;
+    u32 *sT = sR + g.nsr * rw + g.tbl_pad + wave * (32 * NB + 4);
 
-    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid, 0x80808080u);   // signed bytes: pixel - 128
+    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, (int)threadIdx.x, 0x80808080u, (int)blockDim.x);   // signed bytes: pixel - 128
     for (int u = tid; u < 32 * NB; u += 64) sT[u] = (u32)(-(u & 255));
     __syncthreads();
 
     const int xl = tid & 31, h = tid >> 5;
     // byte padl + xl - HALF of a staged row: the window start of pixel xl, and of right position u = xl (block 0)
-    const int ob = g.padl + xl - HALF;
+    const int ob = g.padl + 32 * wave + xl - HALF;
     const int bw = ob >> 2;
     const u32 rho = (u32)(ob & 3);
     const u32 cm = h ? 0xffffffffu : 0u;                // the leaving row's left operand is complemented
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(64, mfma_waves(NB)) void k_ssd_mfma(const u8 *__res
             const i32 vo = __shfl_xor(v, 32), dd = __shfl_xor(d, 32);
             if (vo < v || (vo == v && dd < d)) { v = vo; d = dd; }
             const i32 ll = best ? llk + __shfl_xor(llk, 32) : 0;
-            const int x = xw + xl;
+            const int x = xw + 32 * wave + xl;
             if (h == 0 && x < g.w && !(g.ghost && x < HALF)) {
                 const size_t o = ((size_t)pair * g.h + yk) * g.w + x;
                 web[o] = d + 1;
@@ -290,26 +294,43 @@ const void *sm_ssd_mfma_configure(const sm_plan *plan, int pairs, const void *d_
     if (n < 3 || n > 11 || g.D > 256 || plan->opt.cost_kernel == 1 || plan->opt.cost_kernel == 2) return nullptr;
     const int nb = (g.D + 31 + 31) / 32;                // right positions 0 .. D + 30
     g.nl = 1; g.log2nl = 0; g.nql = 0; g.px = 1; g.q_tail = 0; g.q_last = 0;
-    g.tw = 32;
-    g.tiles_x = (g.w + g.tw - 1) / g.tw;
     g.padl = 4 * ((half + 3 + 3) / 4);
-    // a lane reads 5 dwords from dword (padl + xl - half) / 4 (+ 8 b in the right row)
-    g.lrow = 8 * ((g.padl + 32 + 24 + 7) / 8);
-    g.rrow = 8 * ((g.padl + 32 * nb + 24 + 7) / 8);
-    // the table: 32 nb entries, 16-byte aligned behind the staged rows
-    const int tbl_bytes = 4 * 32 * nb + 16;
-    const int waves = mfma_waves(nb);
-    const int slots = 256 * 4 * waves;
-    int best_th = 0; double best_cost = 0;
-    for (int th = 8; th <= 128; th += 4) {
-        const size_t lds = (size_t)(th + n - 1) * (g.lrow + g.rrow) + tbl_bytes;
-        if (lds > (size_t)(160 * 1024 / (4 * waves))) break;
-        const long long tiles = (long long)g.tiles_x * ((g.h + th - 1) / th) * pairs;
-        const long long rounds = (tiles + slots - 1) / slots;
-        const double cost = (double)rounds * (th + 0.6 * (n - 1) + 2.0);
-        if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
+    const int per_simd = mfma_waves(nb);
+    const int slots = 256 * 4 * per_simd;
+    // workgroup width (1, 2 or 4 waves sharing the staged rows) and tile height together: whole rounds of the waves
+    // the registers allow per SIMD; rows + warm-up (a warm-up row costs ~0.6 of an output row) + staging per wave
+    auto shape = [&](int wv, int *lrow, int *rrow, int *tbl) {
+        // a lane reads 5 dwords from dword (padl + 32 wave + xl - half) / 4 (+ 8 b in the right row)
+        *lrow = 8 * ((g.padl + 32 * wv + 24 + 7) / 8);
+        *rrow = 8 * ((g.padl + 32 * (nb + wv - 1) + 24 + 7) / 8);
+        *tbl = wv * (4 * 32 * nb + 16);      // the tables: 32 nb entries per wave, 16-byte aligned behind the staged rows
+    };
+    // (the plan's own choice is between ONE and FOUR waves: two were measured no better than one at equal tile heights and
+    // slower at the taller tiles the model gives them -- C5: 0.427 / 0.447 / 0.391 ms at 1 / 2 / 4 waves,
+    // profiles/r05/ab_ssd_workgroup_waves.txt -- for a reason that was not found; an explicit 2 is honoured)
+    int best_th = 0, best_wv = 1; double best_cost = 0;
+    for (int wv = 1; wv <= 4; wv *= 2) {
+        if (plan->opt.cost_workgroup_waves ? plan->opt.cost_workgroup_waves != wv : wv == 2) continue;
+        int lrow, rrow, tbl;
+        shape(wv, &lrow, &rrow, &tbl);
+        if (wv > 1 && 32 * wv / 2 >= g.w) break;
+        if (lrow + rrow > 4 * 4 * 64 * wv) continue;         // (the fast staging path's reach)
+        const int tiles_x = (g.w + 32 * wv - 1) / (32 * wv);
+        for (int th = 8; th <= 128; th += 4) {
+            const size_t lds = (size_t)(th + n - 1) * (lrow + rrow) + tbl;
+            if (lds > (size_t)wv * (160 * 1024 / (4 * per_simd)) || lds > 64 * 1024) break;
+            const long long waves = (long long)tiles_x * ((g.h + th - 1) / th) * pairs * wv;
+            const long long rounds = (waves + slots - 1) / slots;
+            const double cost = (double)rounds * (th + 0.6 * (n - 1) + 2.0);
+            if (!best_th || cost < best_cost * (wv > best_wv ? 0.97 : 1.0)) { best_th = th; best_wv = wv; best_cost = cost; }
+        }
     }
     if (!best_th) return nullptr;
+    g.waves = best_wv;
+    int tbl_bytes;
+    shape(g.waves, &g.lrow, &g.rrow, &tbl_bytes);
+    g.tw = 32 * g.waves;
+    g.tiles_x = (g.w + g.tw - 1) / g.tw;
     if (plan->opt.cost_tile_h > 0) {         // an explicit tile height, clamped to what a workgroup's LDS holds
         best_th = plan->opt.cost_tile_h;
         while (best_th > 1 && (size_t)(best_th + n - 1) * (g.lrow + g.rrow) + tbl_bytes > 64 * 1024) best_th--;
@@ -318,7 +339,7 @@ const void *sm_ssd_mfma_configure(const sm_plan *plan, int pairs, const void *d_
     g.tiles_y = (g.h + g.tile_h - 1) / g.tile_h;
     g.nsr = g.tile_h + n - 1;
     g.fast_stage = g.w % 4 == 0 && ((uintptr_t)d_left & 3) == 0 && ((uintptr_t)d_right & 3) == 0 &&
-                   g.lrow + g.rrow <= 4 * 256;
+                   g.lrow + g.rrow <= 4 * 4 * 64 * g.waves;
     // dwords between the end of the staged rows and the table: whatever makes the table 16-byte aligned
     g.rr_stride = 0;
     g.tbl_pad = (4 - (g.nsr * ((g.lrow + g.rrow) >> 2)) % 4) % 4;

@@ -2,7 +2,7 @@
 """Generate DESIGN.md section 6's result tables from the files under profiles/<tag>/ -- nothing in
 them is typed by hand.
 
-    python tools/make_design_tables.py [r04]
+    python tools/make_design_tables.py [r05]
 
 Reads (all written by tools/summarise_profiles.py from one tools/collect_profiles.sh call, i.e. ONE box):
 bench.json, bench_driver_flags.json, bench_graph.json, bench_traced.json, bench_after.json,
@@ -17,7 +17,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
-tag = args_[0] if args_ else "r04"
+tag = args_[0] if args_ else "r05"
 P = ROOT / "profiles" / tag
 
 
@@ -40,8 +40,8 @@ rows = [("default run (`bench.json`: 200 steps, replayed from HIP graphs)", "ben
         ("`--steps 2000`, untraced (`bench_graph.json`)", "bench_graph.json"),
         ("`--steps 2000` UNDER `rocprofv3 --kernel-trace` (`bench_traced.json`)", "bench_traced.json"),
         ("default flags again, after the PMC passes (`bench_after.json`)", "bench_after.json")]
-tab = ["| `bench.py` run, C3 (4K pair, 128 shifts, 9×9, toroidal) | value (M Mpx-disp/s) | ms per step | `roofline.kernel_ms` | VALU instr / launch | `frac` | of sustained |",
-       "|---|---|---|---|---|---|---|"]
+tab = ["| `bench.py` run, C3 (4K pair, 128 shifts, 9×9, toroidal) | value (M Mpx-disp/s) | ms per step | `roofline.kernel_ms` | VALU instr / launch | `frac` | of sustained | `verified` |",
+       "|---|---|---|---|---|---|---|---|"]
 lines = {}
 for label, name in rows:
     d = load(name)
@@ -50,7 +50,7 @@ for label, name in rows:
     lines[name] = d
     r = d["roofline"]
     tab.append(f"| {label} | {d['value'] / 1e6:.2f} | {d['ms_per_step']:.4f} | {r['kernel_ms']:.4f} | "
-               f"{r.get('valu_wave_instructions_per_launch', 0) / 1e6:.2f} M | {r.get('frac')} | {r.get('frac_of_sustained')} |")
+               f"{r.get('valu_wave_instructions_per_launch', 0) / 1e6:.2f} M | {r.get('frac')} | {r.get('frac_of_sustained')} | {d.get('verified')} |")
 if len(tab) > 2:
     out += ["", *tab]
 
@@ -115,7 +115,7 @@ if allc.exists():
         if not l.startswith("{"):
             continue
         d = json.loads(l)
-        w = d['config']['workload'].split(';')[0] + (" — consecutive calls overlapped (`--pipeline`)" if d['config'].get('pipelined') else "")
+        w = d['config']['workload'].split(';')[0] + (" — consecutive steps overlapped (`--overlap`: `sm_run_after`)" if d['config'].get('pipelined') else "")
         t4.append(f"| {w} | {d['ms_per_step']:.4f} ms | {d['roofline']['kernel_ms']:.4f} ms | {d['value'] / 1e6:.2f} |")
     out += ["", *t4]
 
@@ -126,11 +126,25 @@ if d:
     if "cpu_baseline" in d:
         c = d["cpu_baseline"]
         ex.append(f"CPU baseline ({c['kind']}, {c['cores']} core): {c['value']} {c['unit']}" +
-                  (f"; {c['all_cores']['value']} on {c['all_cores']['cores']} threads" if "all_cores" in c else ""))
+                  (f"; {c['all_cores']['value']} on {c['all_cores']['cores']} threads (usable cores: {c['all_cores'].get('usable_cores')}; "
+                   f"rate by thread count {c['all_cores'].get('rate_by_threads')})" if "all_cores" in c else ""))
+    if "verified" in d:
+        v = d.get("verification", {})
+        ex.append(f"`verified` {d['verified']} (maps of the timed steps equal host-launched runs: {v.get('maps_equal_host_launched_runs')}; "
+                  f"band equals the CPU oracle: {v.get('band_equals_cpu_oracle')}; extras: {v.get('extras_verified')})")
+    if "host_launched" in d:
+        ex.append(f"plain host-launched `sm_run`: {d['host_launched']['ms_per_step']} ms per step")
+    if "overlapped" in d and "value" in d["overlapped"]:
+        o = d["overlapped"]
+        ex.append(f"`overlapped` (`sm_run_after`, never `value`): {o['ms_per_step']} ms per step, {o['value'] / 1e6:.2f} M Mpx-disp/s, verified {o['verified']}")
+    if "c2" in d:
+        o = d["c2"]
+        ex.append(f"`c2` (1080p pair, 64 shifts, 7×7): {o['ms_per_step']} ms per step, {o['value'] / 1e6:.2f} M Mpx-disp/s in stream order; "
+                  f"{o['overlapped']['ms_per_step']} ms, {o['overlapped']['value'] / 1e6:.2f} M overlapped; host-launched {o['host_launched_ms_per_step']} ms; verified {o['verified']}")
     for k in ("sad", "ssd", "ssd_c3"):
         if k in d:
             o = d[k]
-            ex.append(f"`{k}` ({o['workload'].split(':')[0]}, parity unpinned): {o['ms_per_launch']} ms per launch, "
+            ex.append(f"`{k}` ({o['workload'].split(':')[0]}, parity unpinned, verified {o.get('verified')}): {o['ms_per_launch']} ms per launch, "
                       f"{o['value'] / 1e6:.2f} M Mpx-disp/s" +
                       (f", VALU frac {o['roofline']['frac']}, {o['roofline']['lane_instructions_per_pixel_shift']} lane-instructions per pixel-shift"
                        if "roofline" in o else ""))
