@@ -122,6 +122,9 @@ def parse(argv=None):
                     help="after the timed region, collect the maps on rank 0 over RCCL and time it")
     ap.add_argument("--no-c2", action="store_true", help="skip the extra `c2` object (N = 1): BASELINE's second single-GPU "
                                                            "configuration (1080p pair, 64 shifts, 7x7), never part of `value`")
+    ap.add_argument("--no-overlapped", action="store_true",
+                    help="skip the extra `overlapped` object (N = 1): runs under rocprofv3 leave it out, so that every traced "
+                         "match launch is one that has the chip to itself, as the launches roofline.kernel_ms is taken from")
     ap.add_argument("--corrupt-map", action="store_true", help=argparse.SUPPRESS)     # test hook: the verification must notice
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the extra `e2e` object (N = 1 only): the PCIe-inclusive rate through the "
@@ -775,6 +778,11 @@ def main():
     n_samples = (args.steps + every - 1) // every
     if graph is None:
         plan.time_kernels(n_samples, every)
+    # (zeroed HERE, in front of the warm-up: whatever the maps hold after the timed region was written by steps issued the way
+    # the timed ones are -- graph replays by default.  Zeroing them right in front of the last burst, 133 MB through the
+    # memset path, left the host-launched timed region 5-10 % slower on the same box: profiles/r05/ab_r04_host_launched.txt)
+    web.zero_()
+    torch.cuda.synchronize(dev)
     warm_t0 = time.perf_counter()
     warm_steps = 0
     while warm_steps < args.warmup or time.perf_counter() - warm_t0 < WARMUP_FLOOR_S:
@@ -797,7 +805,6 @@ def main():
     # region (a timed region of 20 steps is only 2 ms long; without the burst its first
     # launches ran ~10 % slower and the line read 0.099 ms per step where 200 steps read 0.0955)
     burst = gsteps if graph is not None else WARMUP_BURST
-    web.zero_()                 # what the maps hold after the timed region was written by the burst or the timed steps
     run_steps(burst)
     warm_steps += burst
     if graph is None:
@@ -857,7 +864,7 @@ def main():
                                  "timed region"}
     # ---- the same steps through sm_run_after, replayed from a graph of their own: consecutive steps overlap ----------
     overlapped_obj = None
-    if graph is not None and args.serial and not args.pipeline and world == 1:
+    if graph is not None and args.serial and not args.pipeline and world == 1 and not args.no_overlapped:
         try:
             g2 = torch.cuda.CUDAGraph()
             turn[0] = 0
@@ -1049,7 +1056,7 @@ def main():
         "band_equals_cpu_oracle": band_ok,
         "extras_verified": extras_ok,
         "how": f"after the timed region: all {resident} resident result maps, as the timed steps left them (zeroed in front "
-               f"of the last untimed burst), equal (torch.equal, on the device, every rank) the maps of host-launched "
+               f"of the warm-up), equal (torch.equal, on the device, every rank) the maps of host-launched "
                f"unpipelined sm_run calls on the same inputs; rows {vy0} .. {vy0 + verify_rows - 1} of the first one equal "
                f"{how} on the same pair; the `c2` / `sad` / `ssd` objects carry their own checks",
     }

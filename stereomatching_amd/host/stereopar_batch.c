@@ -334,10 +334,12 @@ static void *worker_main(void *arg)
             W_TRY(sm_memcpy_h2d_async(dev, d_in[s] + (size_t)(b + k) * n, w->pairs[j].px[1], n, st_up));
         }
         W_TRY(sm_event_record(dev, ev_up[s], st_up));
-        W_TRY(sm_stream_wait_event(dev, st_run, ev_up[s]));
-        if (used[s]) W_TRY(sm_stream_wait_event(dev, st_run, w->ev_down[s]));
-        W_TRY(sm_run_typed(plan, d_in[s], d_in[s] + (size_t)b * n, w->threshold, b, d_web[s],
-                           web_type, NULL, st_run));
+        /* The batch's kernels wait for ITS upload and for nothing else on st_run (sm_run_after: the event is the call's
+         * only input dependency; round 5) -- the edge detection of this batch may then run beside the match launch of the
+         * one before where that launch leaves room (batches of few small pairs).  The set's map buffer is free: the
+         * collector has waited for the download that last read it (ev_down) before it posted slot_free. */
+        W_TRY(sm_run_after(plan, d_in[s], d_in[s] + (size_t)b * n, w->threshold, b, d_web[s],
+                           web_type, NULL, st_run, ev_up[s]));
         W_TRY(sm_event_record(dev, ev_ran[s], st_run));
         W_TRY(sm_stream_wait_event(dev, st_down, ev_ran[s]));
         W_TRY(sm_memcpy_d2h_async(dev, w->h_web[s], d_web[s], n * web_bytes * b, st_down));

@@ -13,7 +13,7 @@
 # average agrees with the untraced kernel time (bench_traced.json is the traced process's own line).
 set -u
 TAG=${1:-r05}
-F="--no-cpu-baseline --no-e2e --no-cost-modes --no-c2"
+F="--no-cpu-baseline --no-e2e --no-cost-modes --no-c2 --no-overlapped"
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 rm -rf "$OUT"   # gpurun merges results into the build box's copy: delete that one too before a re-run

@@ -14,7 +14,10 @@ from stereomatching_amd.synth import CONFIGS  # noqa: E402
 src = Path(sys.argv[1])
 out = {}
 for f in sorted(src.glob("cost_*_C*.json")):
-    cost, cfg = re.match(r"cost_(sad|ssd)_(C\d)\.json", f.name).groups()
+    m = re.fullmatch(r"cost_(sad|ssd)_(C\d)\.json", f.name)
+    if not m:
+        continue                # (A/B records such as cost_sad_C3_round4_kernel.json)
+    cost, cfg = m.groups()
     d = json.loads(f.read_text())
     w, h, shifts, _, _ = CONFIGS[cfg]
     valu = sum(v for k, v in d["counters_per_launch"].items() if k.endswith("|SQ_INSTS_VALU"))
