@@ -1066,14 +1066,43 @@ def test_cost_kernels_random_shapes_match_own_oracle(hip):
             left[rng.random((h, w)) < 0.2] = 0
             right[rng.random((h, w)) < 0.2] = 255
         ck = 2 if cost == "ssd" and case % 3 == 1 else 0         # SSD: a third of the cases on the byte-dot kernel
-        plan = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_tile_h=th, cost_kernel=ck))
+        if cost == "sad" and case % 5 == 2:
+            ck = 4                                               # SAD: a fifth on the round-4 kernel (every window row from scratch)
+        wv = int(rng.choice([0, 0, 1, 2, 4]))                    # waves per workgroup sharing the staged rows (round 5)
+        plan = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_tile_h=th, cost_kernel=ck, cost_workgroup_waves=wv))
         web, best = plan.cost_wta(dev(left), dev(right), cost)
         ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, cost)
-        assert np.array_equal(host(web)[0], ow), (case, w, h, d, sw, mode, cost, th)
-        assert np.array_equal(host(best)[0], ob), (case, w, h, d, sw, mode, cost, th)
+        assert np.array_equal(host(web)[0], ow), (case, w, h, d, sw, mode, cost, th, ck, wv)
+        assert np.array_equal(host(best)[0], ob), (case, w, h, d, sw, mode, cost, th, ck, wv)
         plan.close()
     if soak:
         print(f"cost soak: {soak} cases, all equal to the build's own CPU definition")
+
+
+@pytest.mark.parametrize("mode", ["toroidal", "ghost"])
+@pytest.mark.parametrize("cost", ["sad", "ssd"])
+def test_cost_workgroups_of_several_waves_share_their_rows(hip, mode, cost):
+    """k_sad_pc / k_ssd_mfma in workgroups of 1, 2 and 4 waves (round 5: the waves stage one set of rows and share it --
+    one right-image span for all of them): images a few workgroups wide and not a multiple of any workgroup width,
+    shift counts that give 1 .. 16 shift lanes per pixel group (SAD) and 1 .. 9 position blocks (SSD), tiles of the
+    plan's height and of 5 rows, web and best against the CPU definition; the plan's own choice equals them all."""
+    rng = np.random.default_rng(61)
+    for sw, d, w, h in ((9, 128, 700, 41), (11, 256, 452, 33), (7, 64, 1030, 27), (5, 16, 530, 19), (13, 200, 390, 29),
+                        (3, 500 if cost == "sad" else 250, 300, 17)):
+        left = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        right = np.roll(left, int(rng.integers(0, min(d, w))), 1)
+        right = np.clip(right.astype(np.int32) + rng.integers(-2, 3, (h, w)), 0, 255).astype(np.uint8)
+        left[::5, ::9] = 0; right[1::4, 3::7] = 255
+        if cost == "ssd" and sw > 11:
+            continue
+        ob, ow = oracle.cost_hot_path(left, right, d, sw, mode, cost)
+        for wv in (0, 1, 2, 4):
+            for th in (0, 5):
+                plan = hip.StereoPlan(w, h, d, sw, mode, options=dict(cost_workgroup_waves=wv, cost_tile_h=th))
+                web, best = plan.cost_wta(dev(left), dev(right), cost)
+                assert np.array_equal(host(web)[0], ow), (cost, mode, sw, d, w, wv, th)
+                assert np.array_equal(host(best)[0], ob), (cost, mode, sw, d, w, wv, th)
+                plan.close()
 
 
 @pytest.mark.parametrize("mode", ["toroidal", "ghost"])
@@ -1236,7 +1265,40 @@ def test_soak_random_pipelines(hip):
             web, best = plan.run(dl, dr, thr, want_best=True)
             torch.cuda.synchronize()
             assert torch.equal(narrow.to(torch.int32), web), (case, "narrow map of the pipelined runs", plan.describe())
+            if case % 3 == 0:
+                # round 5: the same lanes INSIDE a HIP graph (forked and joined by the capture's own events), replayed
+                # twice with an eager call in between
+                plan.reserve_narrow()
+                gw = [plan._new(pairs, torch.int32) for _ in range(3)]
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    for o in gw:
+                        plan.run(dl, dr, thr, want_best=False, web=o)
+                for rep in range(2):
+                    for o in gw:
+                        o.zero_()
+                    g.replay()
+                    torch.cuda.synchronize()
+                    for o in gw:
+                        assert torch.equal(o, web), (case, "graph replay of pipelined runs", rep, plan.describe())
+                    plan.run(dl, dr, thr, want_best=False, web=maps[0])
+                del g
             plan.set_pipelined(0)
+        elif case % 4 == 1:
+            # round 5: sm_run_after behind an upload on a copy stream (its event the only input dependency), three calls
+            # into three maps, then the compared one
+            dl, dr = torch.zeros_like(dev(left)), torch.zeros_like(dev(right))
+            hl, hr = torch.from_numpy(left).pin_memory(), torch.from_numpy(right).pin_memory()
+            copy = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(copy):
+                dl.copy_(hl, non_blocking=True); dr.copy_(hr, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(copy)
+            extra = [plan.run_after(dl, dr, thr, inputs_ready=ev)[0] for _ in range(3)]
+            web, best = plan.run_after(dl, dr, thr, inputs_ready=ev, want_best=True)
+            torch.cuda.synchronize()
+            for o in extra:
+                assert torch.equal(o, web), (case, "sm_run_after", plan.describe())
         else:
             web, best = plan.run(dev(left), dev(right), thr, want_best=True)
         el, er = plan.find_all_edges(dev(left), dev(right), thr)
