@@ -153,3 +153,18 @@ def test_bench_timing_stride_samples_enough_launches():
         every = bench.timing_stride(steps)
         assert 1 <= every <= 8
         assert (steps + every - 1) // every >= min(steps, 10)
+
+
+def test_bench_fails_fast_when_a_rank_never_shows_up():
+    """Round 5 (first-run readiness): a rank whose peers do not join -- a missing device, a communicator that does not
+    come up -- must not hang the job: the rendezvous gives up after SM_BENCH_INIT_TIMEOUT seconds, rank 0 still prints
+    ONE line, with `error` and value 0, and exits 4."""
+    import time
+    t0 = time.time()
+    p, lines = _bench(["--gpus", "2", "--config", "C4", "--steps", "2", "--warmup", "1"], SM_BENCH_DRYRUN="1",
+                      RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577",
+                      SM_BENCH_INIT_TIMEOUT="4")
+    assert p.returncode == 4, (p.returncode, p.stderr[-1500:])
+    assert time.time() - t0 < 120
+    assert len(lines) == 1 and lines[0]["value"] == 0.0 and lines[0]["verified"] is False
+    assert "did not come up within 4 s" in lines[0]["error"] and "InitError" in lines[0]["error"]
