@@ -852,9 +852,11 @@ def main():
         # ... and the rate of the plain host-launched path beside the default's (both in the line)
         turn[0] = 0
         n_hl = max(resident, min(args.steps, 200))
-        for _ in range(WARMUP_BURST):
-            step(serial=True)
-        torch.cuda.synchronize(dev)
+        t_end = time.perf_counter() + WARMUP_FLOOR_S       # (the checks above left the chip idle: clocks ramp up again first)
+        while time.perf_counter() < t_end:
+            for _ in range(WARMUP_BURST):
+                step(serial=True)
+            torch.cuda.synchronize(dev)
         h0 = time.perf_counter()
         for _ in range(n_hl):
             step(serial=True)
