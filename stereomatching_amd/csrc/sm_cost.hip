@@ -22,6 +22,7 @@
 
 #include "sm_internal.h"
 #include "sm_cost.h"
+#include <mutex>
 
 #define SMC_DS 8        // shifts per lane
 #define SMC_PX 4        // pixels per lane
@@ -343,8 +344,10 @@ extern "C" int sm_cost_wta(sm_plan *plan, const uint8_t *d_gray_left, const uint
             void *args[] = {(void *)&d_gray_left, (void *)&d_gray_right, (void *)&d_web, (void *)&d_best, (void *)&q};
             if (q.lds_bytes > 64 * 1024) {
                 // (four-wave workgroups of k_sad_pc: up to 80 of the CU's 160 KB; the limit is raised once per kernel)
+                static std::mutex guard;          // (plans on different host threads may launch the same kernel)
                 static const void *raised[8];
                 static int n_raised = 0;
+                std::lock_guard<std::mutex> lock(guard);
                 bool seen = false;
                 for (int i = 0; i < n_raised; i++) seen = seen || raised[i] == fn;
                 if (!seen) {

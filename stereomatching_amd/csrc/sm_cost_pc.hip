@@ -279,18 +279,31 @@ __global__ __launch_bounds__(256, 2) void k_sad_pc(const u8 *__restrict__ left, 
         quad(quad, std::integral_constant<int, 0>{});
 
         if (OUT) {
+            u32 key[PX];
 #pragma unroll
             for (int i = 0; i < PX; i++) {
                 u32 run = runc[0][i];
 #pragma unroll
                 for (int c = 1; c < NCH; c++) run = min(run, runc[c][i] + (u32)(4 * CH * c));
-                u32 key = run + (u32)dconst;                // the low half becomes the shift itself (>= 0 for a winner)
-                for (int k = 0; k < g.log2nl; k++) key = min(key, (u32)__shfl_xor((int)key, 4 << k));
-                const int x = x0 + 4 * i;
-                if (sl == 0 && x < g.w) {
-                    const size_t o = ((size_t)pair * g.h + y) * g.w + x;
-                    web[o] = (i32)(key & 0xffffu) + 1;
-                    if (best) best[o] = (i32)(key >> 16);
+                key[i] = run + (u32)dconst;                 // the low half becomes the shift itself (>= 0 for a winner)
+            }
+            // the shift lanes of a pixel group: all PX exchanges of a level in flight together (one wait per level, not per pixel)
+            for (int k = 0; k < g.log2nl; k++) {
+                u32 other[PX];
+#pragma unroll
+                for (int i = 0; i < PX; i++) other[i] = (u32)__shfl_xor((int)key[i], 4 << k);
+#pragma unroll
+                for (int i = 0; i < PX; i++) key[i] = min(key[i], other[i]);
+            }
+            if (sl == 0) {
+                i32 *wrow = web + ((size_t)pair * g.h + y) * g.w + x0;
+                i32 *brow = best ? best + ((size_t)pair * g.h + y) * g.w + x0 : nullptr;
+#pragma unroll
+                for (int i = 0; i < PX; i++) {
+                    if (x0 + 4 * i < g.w) {
+                        wrow[4 * i] = (i32)(key[i] & 0xffffu) + 1;
+                        if (brow) brow[4 * i] = (i32)(key[i] >> 16);
+                    }
                 }
             }
         }
