@@ -679,6 +679,18 @@ def test_run_after_an_input_ready_event(hip):
         torch.cuda.synchronize()
         for i in range(len(pairs)):
             assert np.array_equal(host(webs[i])[0], want[i]), (rep, i)
+    # argument checks as sm_run's
+    import ctypes as C
+    lib = hip.capi.lib
+    assert lib.sm_run_after(plan._h, C.c_void_p(dl[0].data_ptr()), C.c_void_p(dr[0].data_ptr()), 0.15, 2,
+                            C.c_void_p(webs[0].data_ptr()), 0, None, None, None) == hip.capi.SM_ERR_ARG      # pairs > max_pairs
+    assert lib.sm_run_after(None, None, None, 0.15, 1, None, 0, None, None, None) == hip.capi.SM_ERR_ARG
+    assert lib.sm_run_after(plan._h, C.c_void_p(dl[0].data_ptr()), C.c_void_p(dr[0].data_ptr()), 1.5, 1,
+                            C.c_void_p(webs[0].data_ptr()), 0, None, None, None) == hip.capi.SM_ERR_ARG      # threshold
+    assert lib.sm_run_after(plan._h, C.c_void_p(dl[0].data_ptr()), C.c_void_p(dr[0].data_ptr()), 0.15, 1,
+                            None, 0, None, None, None) == hip.capi.SM_ERR_ARG                                   # no map
+    # ... and a refused call leaves the plan usable (the lanes were not touched, or were joined)
+    assert np.array_equal(host(plan.run_after(dl[2], dr[2], 0.15)[0])[0], want[2])
     # mixed with plain runs, a changing threshold and ONE shared map: still ordered
     one = torch.zeros((1, h, w), dtype=torch.int32, device="cuda")
     for i in range(len(pairs)):
