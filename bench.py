@@ -347,6 +347,10 @@ def cost_modes(dev):
                              "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s", "frac": round(ach / VALU_PEAK_GIPS, 4),
                              "valu_wave_instructions_per_launch": c["valu_wave_instructions"],
                              "lane_instructions_per_pixel_shift": round(c["valu_wave_instructions"] * 64.0 / (float(w) * h * d), 2),
+                             **({"v_qsad_lane_instructions_per_pixel_shift": c["v_qsad_lane_instructions_per_pixel_shift"],
+                                 "qsad_note": "of the lane-instructions; each issues over four passes, the others over one "
+                                              "(SQ_ACTIVE_INST_VALU - SQ_INSTS_VALU = 3 x their number)"}
+                                if "v_qsad_lane_instructions_per_pixel_shift" in c else {}),
                              "source": c.get("source")}
             if c.get("mfma_i8_instructions"):
                 # the SSD kernel's products run on the matrix cores (v_mfma_i32_32x32x32_i8, 65 536 operations each);

@@ -21,6 +21,7 @@ for f in sorted(src.glob("cost_*_C*.json")):
     d = json.loads(f.read_text())
     w, h, shifts, _, _ = CONFIGS[cfg]
     valu = sum(v for k, v in d["counters_per_launch"].items() if k.endswith("|SQ_INSTS_VALU"))
+    active = sum(v for k, v in d["counters_per_launch"].items() if k.endswith("|SQ_ACTIVE_INST_VALU"))
     mfma = sum(v for k, v in d["counters_per_launch"].items() if k.endswith("|SQ_INSTS_VALU_MFMA_I8"))
     names = [re.sub(r"^void ", "", k["Name"]).split("(")[0] for k in d["kernel_stats"]]
     out[f"{cfg}:{cost}"] = {
@@ -30,6 +31,13 @@ for f in sorted(src.glob("cost_*_C*.json")):
         "lane_instructions_per_pixel_shift": round(valu * 64 / (float(w) * h * shifts), 2),
         "source": f"{f.relative_to(ROOT) if f.is_absolute() else f} (rocprofv3 --pmc SQ_INSTS_VALU, separate passes)",
     }
+    if cost == "sad" and active > valu:
+        # the quad-SAD instructions issue over four passes, every other VALU instruction over one (tools/ubench_sad.hip), and
+        # SQ_ACTIVE_INST_VALU counts passes: (passes - instructions) / 3 of them are v_qsad / v_mqsad
+        q = (active - valu) / 3.0
+        out[f"{cfg}:{cost}"]["qsad_wave_instructions"] = int(round(q))
+        out[f"{cfg}:{cost}"]["v_qsad_lane_instructions_per_pixel_shift"] = round(q * 64 / (float(w) * h * shifts), 3)
+        out[f"{cfg}:{cost}"]["valu_issue_passes"] = int(round(active))
     if mfma:            # v_mfma_i32_32x32x32_i8: 2 x 32 x 32 x 32 operations each
         out[f"{cfg}:{cost}"]["mfma_i8_instructions"] = int(round(mfma))
 order = ["C3:sad", "C5:sad", "C3:ssd", "C5:ssd"]
