@@ -39,6 +39,10 @@
 #include "sm_cost.h"
 #include <type_traits>
 
+#ifndef PC_EXP
+#define PC_EXP 0        // (timing experiments only, results wrong: 1 rows not loaded from memory, 2 no arg-min keys, 3 no E / shifted rows per step)
+#endif
+
 typedef unsigned long long u64;
 typedef unsigned short v4h __attribute__((ext_vector_type(4)));
 
@@ -100,7 +104,11 @@ __global__ __launch_bounds__(256, 2) void k_sad_pc(const u8 *__restrict__ left, 
     // ---- stage the tile's rows (+ window halo) with the border rule applied
     // (all waves of the workgroup -- one, two or four, each with its own pixel groups -- stage and share the rows)
     const int nthreads = blockDim.x;
+#if PC_EXP != 1
     smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid, 0, nthreads);
+#else
+    for (int k = tid; k < g.nsr * (lw + rw); k += nthreads) lds[k] = (u32)k * 2654435761u;
+#endif
     __syncthreads();
 
     // ---- lane role: residue a, shift-lane sl, pixel group j (over all waves)
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void k_sad_pc(const u8 *__restrict__ left, 
 
         // per right dword position: E = (bytes the zeroed left bytes pick up in the new row) - (old row), and the
         // two rows RB bytes further on
-        for (int k = tid; k < rw - 1; k += nthreads) {
+        for (int k = tid; k < (PC_EXP == 3 ? 0 : rw - 1); k += nthreads) {
             const u32 n0 = rowRn[k], n1 = rowRn[k + 1];
             const u64 mn = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)n1 << 32) | n0, MASKC, 0ull);   // 255 (4-RB) - T_new
             sSn[k] = __builtin_amdgcn_alignbyte(n1, n0, RB);
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_sad_pc(const u8 *__restrict__ left, 
                     // (pinned: nothing of a quad may sink below the quads nested in it)
                     asm volatile("" : : "v"(acc));
                     W[i][q] = acc;
-                    if (OUT) {
+                    if (OUT && PC_EXP != 2) {
                         constexpr int cq = 4 * (q % CH);
                         const u32 lo = (u32)acc, hi = (u32)(acc >> 32);
                         u32 k0 = (lo << 16) | (u32)cq, k1 = bop_and_or(lo, 0xffff0000u, (u32)(cq + 1));
