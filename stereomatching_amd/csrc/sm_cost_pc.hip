@@ -104,8 +104,14 @@ __global__ __launch_bounds__(256, 2) void k_sad_pc(const u8 *__restrict__ left, 
     // ---- stage the tile's rows (+ window halo) with the border rule applied
     // (all waves of the workgroup -- one, two or four, each with its own pixel groups -- stage and share the rows)
     const int nthreads = blockDim.x;
+    // Two rows before the first step; row s + 2 is fetched at step s and written to LDS at step s + 1, whose barrier
+    // publishes it in time for step s + 2 (smc_stage_rows' slow path -- odd widths, unaligned images -- stages everything here).
+    // (the 17-quad builds only: the column pointers cost the smaller ones their third wave per SIMD)
+    const bool stream = NQL >= 17 && g.fast_stage != 0;
+    SmcStream feed;
+    if (stream) feed.setup(L, R, g, xw, tid, nthreads);
 #if PC_EXP != 1
-    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid, 0, nthreads);
+    smc_stage_rows(lds, L, R, g, xw, ty0, HALF, tid, 0, nthreads, stream ? 2 : g.nsr);
 #else
     for (int k = tid; k < g.nsr * (lw + rw); k += nthreads) lds[k] = (u32)k * 2654435761u;
 #endif
@@ -144,6 +150,11 @@ __global__ __launch_bounds__(256, 2) void k_sad_pc(const u8 *__restrict__ left, 
         const u32 *rowLn = sL + rn_i * lw, *rowRn = sR + rn_i * rw;
         const u32 *rowLo = sL + ro_i * lw, *rowRo = sR + ro_i * rw;
 
+        // the row fetched at the step before goes to LDS, the row two steps ahead is asked for (rn_i is the step's number)
+        if (stream && PC_EXP != 1) {
+            feed.store(lds);
+            if (rn_i + 2 < g.nsr) feed.fetch(g, ty0, HALF, rn_i + 2);
+        }
         // per right dword position: E = (bytes the zeroed left bytes pick up in the new row) - (old row), and the
         // two rows RB bytes further on
         for (int k = tid; k < (PC_EXP == 3 ? 0 : rw - 1); k += nthreads) {
