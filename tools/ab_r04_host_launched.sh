@@ -1,6 +1,8 @@
 #!/bin/bash
 # Same-box A/B of the HOST-LAUNCHED bench path between the round-4 tree (a git worktree under tmp_r04/, built there) and this one,
 # and the crossing: round 4's bench.py on THIS tree's library.   gpurun -- 'bash tools/ab_r04_host_launched.sh'
+# Before:  git worktree add -f tmp_r04 8d9a0b8 && (cd tmp_r04 && python -m stereomatching_amd.build)   -- the worktree must lie
+# inside the repository to travel with gpurun; remove it afterwards (git worktree remove --force tmp_r04), it is not tracked.
 F="--no-graph --no-cpu-baseline --no-e2e --no-cost-modes"
 q='import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["roofline"]["kernel_ms"])'
 for rep in 1 2 3; do
