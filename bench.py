@@ -739,7 +739,7 @@ def main():
                                    C.c_void_p(0)))
     geo0 = plan.geometry()
     overlapped = bool(args.pipeline) or (not args.serial and
-                                         geo0["tiles_x"] * geo0["tiles_y"] * pairs * max(1, geo0["threads"] // 64) < 2048)
+                                         geo0["tiles_x"] * geo0["tiles_y"] * pairs * max(1, geo0["threads"] // 64) < 2048 and d <= 128)
 
     # --graph: `gsteps` consecutive steps (a whole number of turns over the resident batches) captured once
     graph, gsteps, graph_note = None, 0, None

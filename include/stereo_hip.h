@@ -301,7 +301,8 @@ int sm_run(sm_plan *plan, const uint8_t *d_gray_left,
  * results.  That freedom is what lets consecutive calls overlap, and the plan takes it by itself: a match launch of
  * fewer than 2 x 1024 waves (a lone pair up to 4K: it cannot fill the chip twice over, and the next call's edge
  * detection and first waves fit beside its tail) runs on the plan's two internal lanes as under
- * sm_plan_set_pipelined(1); larger launches run in `stream` order behind the event.  Give consecutive calls their
+ * sm_plan_set_pipelined(1); larger launches, and plans of more than 128 shifts (the edge detection the overlap hides is a small
+ * part of their step, and two calls sharing the chip cost more than it), run in `stream` order behind the event.  Give consecutive calls their
  * own result maps.  Inside a stream capture the event must be one recorded in the same capture.                    */
 int sm_run_after(sm_plan *plan, const uint8_t *d_gray_left, const uint8_t *d_gray_right,
                  double threshold, int pairs, void *d_web, int web_type, int32_t *d_best,

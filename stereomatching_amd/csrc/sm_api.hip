@@ -1377,7 +1377,10 @@ extern "C" int sm_run_after(sm_plan *plan, const uint8_t *d_gray_left, const uin
     SM_TRY(check_plan_pairs(plan, pairs, "sm_run_after"));
     const MatchGeom &g = plan->g;
     const long long waves = (long long)g.tiles_x * g.tiles_y * pairs * ((g.threads + 63) / 64);
-    if (!plan->pipelined && waves >= 2 * 1024) {
+    // (... and no more than 128 shifts: the edge detection the overlap hides is then a ninth of a step or more.  At 256 shifts --
+    // C5: a 158 us match launch beside 15 us of edges -- two calls sharing the chip cost more than that: 0.1782 against 0.1755 ms
+    // per step, where C3 gains 2.6 % and C1 / C2 9-19 %: profiles/r05/bench_all_configs.txt)
+    if (!plan->pipelined && (waves >= 2 * 1024 || plan->num_shifts > 128)) {
         SM_TRY(use_device(plan->device));
         if (inputs_ready_event) SM_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)inputs_ready_event, 0));
         SM_TRY(sm_find_edges(plan, d_gray_left, d_gray_right, threshold, pairs, nullptr, nullptr, stream));
