@@ -34,6 +34,17 @@
 //
 // Ghost border: as k_sad_qs -- zero staging outside the image, the columns x < half recomputed by
 // sm_cost_strip.hip behind this launch.
+//
+// What else the row loop does NOT pay for (each measured, docs/HISTORY_round5.md section 1):
+//   - shifts that do not exist (below 0: a pixel's quads start at -rho; from D on): windows up to 11 x 11 start their sums
+//     at a constant no real sum reaches (POISON), so no validity test is left in the loop -- the tests of the checked quads,
+//     hoisted by the compiler into every quad, had eaten what the first version saved;
+//   - W + P is one 64-bit add where no field can carry (windows up to 9 x 9: ADD64);
+//   - the tile's rows are fetched WHILE it is worked on (SmcStream, sm_cost.h): two rows before the first step, row s + 2
+//     asked for at step s -- staging all rows first was 5 % of a one-round launch (profiles/r05/ab_sad_knockouts.txt);
+//   - workgroups of 1, 2 or 4 waves share the staged rows (the host chooses: at 256 shifts four waves slide 64 rows where a
+//     lone wave's 20 KB hold 16).
+// PC_EXP: timing knock-outs (results wrong), as MFMA_EXP of sm_cost_mfma.hip.
 
 #include "sm_internal.h"
 #include "sm_cost.h"
