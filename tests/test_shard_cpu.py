@@ -168,3 +168,28 @@ def test_bench_fails_fast_when_a_rank_never_shows_up():
     assert time.time() - t0 < 120
     assert len(lines) == 1 and lines[0]["value"] == 0.0 and lines[0]["verified"] is False
     assert "did not come up within 4 s" in lines[0]["error"] and "InitError" in lines[0]["error"]
+
+
+def test_bench_under_the_drivers_own_launcher():
+    """The command the driver issues for N > 1, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` (torchrun sets RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*; bench.py must not start ranks of its own then).  Dry run: no GPU here."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SM_BENCH_DRYRUN"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+                        "--gpus", "2", "--steps", "5", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["dry_run"] is True
+    assert out["c4"]["pairs_per_rank"] == 32 and out["c4"]["maps_in_pair_order"] is True
